@@ -1,0 +1,35 @@
+# Builds libxlbhip.so (HIP, gfx950) and the C oracle.  No cmake: hipcc/gcc directly.
+HIPCC     ?= /opt/rocm/bin/hipcc
+ARCH      ?= gfx950
+CSRC      := xlb_amd/csrc
+OBJDIR    := build/obj
+LIB       := xlb_amd/lib/libxlbhip.so
+# -ffp-contract=off: fp32/fp64 results are bit-identical to the oracle's operation order
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
+SRCS      := api.hip comm.cpp step_d2q9_bgk.hip step_d2q9_kbc.hip step_d3q19_bgk.hip step_d3q27_bgk.hip step_d3q27_kbc.hip
+OBJS      := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(basename $(SRCS))))
+HDRS      := $(wildcard $(CSRC)/*.hpp) include/xlbhip.h
+
+all: $(LIB) oracle
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p xlb_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
+
+oracle: oracle/liblbmref.so
+
+oracle/liblbmref.so: oracle/lbm_ref.c oracle/lbm_ref_body.inc
+	gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off -fno-fast-math -o $@ $< -lm
+
+clean:
+	rm -rf build xlb_amd/lib/libxlbhip.so oracle/liblbmref.so
+
+.PHONY: all oracle clean

@@ -1,0 +1,163 @@
+/*
+ * xlbhip.h — C ABI of the MI355X-native LBM stepper (libxlbhip.so).
+ *
+ * This is the drop-in boundary for the per-timestep hot path of hsalehipour/XLB.
+ * The reference has no native code: its "FFI" for this path is the set of Python
+ * methods registered with @Operator.register_backend(ComputeBackend.X)
+ * (reference xlb/operator/operator.py:74-133).  Every entry point below names the
+ * reference method(s) whose body a `hip_implementation` replaces; the ctypes stub a
+ * maintainer would add is shown in INTEGRATION.md and shipped in xlb_amd/_lib.py.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every call returns 0 on success, non-zero on failure; the message is available
+ *    from xlbhip_last_error() (thread-local).  The Python shim turns it into an
+ *    exception, mirroring the reference's exception-only error model
+ *    (operator.py:128-133).
+ *  - calls only ENQUEUE work on the context's compute stream (asynchronous, like
+ *    wp.launch in the reference) except *_download, *_sync and *_timed.
+ *  - host arrays are C-order (cardinality, nx, ny, nz), population index slowest,
+ *    last spatial axis fastest — the reference layout (xlb/grid/warp_grid.py:26,
+ *    xlb/grid/jax_grid.py:44-46).  2-D grids (nx, ny) are passed as (1, nx, ny):
+ *    the lattice's two components then act on the last two axes.
+ */
+#ifndef XLBHIP_H
+#define XLBHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xlbhip_ctx xlbhip_ctx;
+typedef struct xlbhip_field xlbhip_field;
+typedef struct xlbhip_stepper xlbhip_stepper;
+
+/* element types of a field; mirrors Precision in xlb/precision_policy.py:13-54 */
+enum {
+  XLBHIP_F64 = 0,
+  XLBHIP_F32 = 1,
+  XLBHIP_F16 = 2,
+  XLBHIP_U8 = 3,
+  XLBHIP_BOOL = 4,      /* one byte per element, 0/1 */
+  XLBHIP_MISSING = 5    /* missing_mask: host view (q,nx,ny,nz) u8 0/1; device: one u32 bit-set per cell */
+};
+
+/* velocity sets; xlb/velocity_set/{d2q9,d3q19,d3q27}.py */
+enum { XLBHIP_D2Q9 = 0, XLBHIP_D3Q19 = 1, XLBHIP_D3Q27 = 2 };
+
+/* collision models; xlb/operator/stepper/nse_stepper.py:78-84 */
+enum { XLBHIP_BGK = 0, XLBHIP_KBC = 1 };
+
+/* boundary-condition kinds (in scope: SURVEY.md section 8 rows a7-a9, + DoNothing) */
+enum {
+  XLBHIP_BC_EQUILIBRIUM = 1,  /* bc_equilibrium.py:72-80   (post-streaming) */
+  XLBHIP_BC_HALFWAY_BB = 2,   /* bc_halfway_bounce_back.py:116-134 (post-streaming) */
+  XLBHIP_BC_FULLWAY_BB = 3,   /* bc_fullway_bounce_back.py:50-56   (post-collision) */
+  XLBHIP_BC_DO_NOTHING = 4    /* bc_do_nothing.py:50-54    (post-streaming) */
+};
+
+/* One boundary condition as the stepper sees it.  `values` holds, in COMPUTE
+ * precision widened to double (exactly representable): for EQUILIBRIUM the q
+ * populations feq(rho0,u0); for HALFWAY_BB the q moving-wall terms
+ * 6 w_l (c_l . u_wall) (all zero for no-slip).  Computed on the host by the
+ * Python operator exactly as the reference's JAX branch does. */
+typedef struct {
+  int32_t id;        /* value in bc_mask, 1..253; boundary_condition_registry.py:16-27 */
+  int32_t kind;      /* XLBHIP_BC_* */
+  double values[27];
+} xlbhip_bc_desc;
+
+/* ---- context ------------------------------------------------------------ */
+/* replaces: xlb.init backend branch, xlb/default_config.py:78-100 */
+int xlbhip_create(int device, xlbhip_ctx** out);
+int xlbhip_destroy(xlbhip_ctx* ctx);
+int xlbhip_sync(xlbhip_ctx* ctx);                 /* wp.synchronize(), mlups_3d.py:230 */
+const char* xlbhip_last_error(void);
+int xlbhip_device_info(xlbhip_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes);
+/* tuning knobs (kernel variant selection etc.); unknown keys are an error */
+int xlbhip_set_option(xlbhip_ctx* ctx, const char* key, int64_t value);
+int xlbhip_get_option(xlbhip_ctx* ctx, const char* key, int64_t* value);
+
+/* lattice tables as compiled into the kernels, for cross-checking against the
+ * Python VelocitySet (velocity_set.py:63-83): c is (3,q) row-major (2-D sets have a
+ * leading zero row), w (q), opp (q), cc (q,6) */
+int xlbhip_lattice_info(int lattice, int* d, int* q, int32_t* c, double* w, int32_t* opp, int32_t* cc);
+
+/* ---- fields ------------------------------------------------------------- */
+/* replaces: WarpGrid.create_field, xlb/grid/warp_grid.py:17-35.
+ * halo = number of ghost x-planes on each side (0, or 1 for slab-decomposed runs). */
+int xlbhip_field_create(xlbhip_ctx* ctx, int cardinality, int nx, int ny, int nz, int dtype, int halo,
+                        double fill_value, xlbhip_field** out);
+int xlbhip_field_destroy(xlbhip_field* f);
+int xlbhip_field_fill(xlbhip_field* f, double value);
+int xlbhip_field_copy(xlbhip_field* dst, const xlbhip_field* src);            /* wp.copy, nse_stepper.py:124 */
+int xlbhip_field_upload(xlbhip_field* f, const void* host, size_t host_bytes);   /* interior only */
+int xlbhip_field_download(const xlbhip_field* f, void* host, size_t host_bytes); /* interior only; synchronous */
+int xlbhip_field_info(const xlbhip_field* f, int* cardinality, int* nx, int* ny, int* nz, int* dtype, int* halo,
+                      uint64_t* plane_stride_elems, void** device_ptr);
+
+/* ---- whole-field operators (kernel-backend out-of-place style) ---------- */
+/* Stream()(f_0, f_1): stream.py:96-125 */
+int xlbhip_stream(xlbhip_ctx* ctx, int lattice, const xlbhip_field* f_src, xlbhip_field* f_dst);
+/* QuadraticEquilibrium()(rho, u, f): quadratic_equilibrium.py:23-30, :91-103 */
+int xlbhip_equilibrium(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_field* rho, const xlbhip_field* u,
+                       xlbhip_field* f);
+/* Macroscopic()(f, rho, u): macroscopic.py:21-26, :57-64 */
+int xlbhip_macroscopic(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_field* f, xlbhip_field* rho,
+                       xlbhip_field* u);
+/* SecondMoment()(f, pi): second_moment.py:35-55 */
+int xlbhip_second_moment(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_field* f, xlbhip_field* pi);
+/* BGK()/KBC()(f, feq, fout, omega): bgk.py:27-32,:78-91; kbc.py:40-79 */
+int xlbhip_collide(xlbhip_ctx* ctx, int lattice, int collision, int compute_dtype, const xlbhip_field* f,
+                   const xlbhip_field* feq, xlbhip_field* fout, double omega);
+/* bc(f_pre, f_post, bc_mask, missing_mask) -> f_post (in place): boundary_condition.py:146-180 */
+int xlbhip_apply_bc(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_bc_desc* bc, const xlbhip_field* f_pre,
+                    xlbhip_field* f_post, const xlbhip_field* bc_mask, const xlbhip_field* missing_mask);
+
+/* ---- boundary masker ----------------------------------------------------- */
+/* replaces: IndicesBoundaryMasker (JAX semantics), indices_boundary_masker.py:73-143.
+ * For BC i: tag_idx[i] is an int32 (3, tag_count[i]) row-major array of GLOBAL cell
+ * indices that receive bc_ids[i] in bc_mask (later BCs overwrite earlier ones);
+ * solid_idx[i] (may be NULL / count 0) are GLOBAL indices whose every population is
+ * marked missing before the mask is streamed (the "interior geometry" branch,
+ * :107-121).  global_shape is the whole domain; x_offset is the global x index of this
+ * rank's first interior plane (the start_index of :76,:106).  Existing contents of
+ * missing_mask are streamed too, as in the reference. */
+int xlbhip_build_masks(xlbhip_ctx* ctx, int lattice, int n_bc, const int32_t* bc_ids, const int32_t* const* tag_idx,
+                       const int64_t* tag_count, const int32_t* const* solid_idx, const int64_t* solid_count,
+                       const int32_t global_shape[3], int x_offset, xlbhip_field* bc_mask, xlbhip_field* missing_mask);
+
+/* ---- the stepper (the hot path) ------------------------------------------ */
+/* replaces: IncompressibleNavierStokesStepper._construct_warp + launch,
+ * nse_stepper.py:335-476, with the JAX step order of :237-282. */
+int xlbhip_stepper_create(xlbhip_ctx* ctx, int lattice, int collision, int compute_dtype, int store_dtype, int n_bc,
+                          const xlbhip_bc_desc* bcs, xlbhip_stepper** out);
+int xlbhip_stepper_destroy(xlbhip_stepper* s);
+/* one step: reads f_src, writes f_dst (caller swaps); omega is cast to compute dtype (bgk.py:31) */
+int xlbhip_step(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_dst, const xlbhip_field* bc_mask,
+                const xlbhip_field* missing_mask, double omega, int64_t timestep);
+/* n_steps steps with the A/B swap done natively; the result is in f_a if n_steps is even, else f_b */
+int xlbhip_run(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
+               const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps);
+/* as xlbhip_run, bracketed by HIP events on the compute stream; returns device ms for the whole loop */
+int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
+                     const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps,
+                     float* device_ms);
+
+/* ---- slab decomposition over ranks (one process per GPU) ------------------ */
+/* semantics reference: xlb/distribute/distribute.py:18-48 (ring exchange of the
+ * face-crossing populations along the slowest spatial axis). */
+#define XLBHIP_UNIQUE_ID_BYTES 128
+int xlbhip_comm_unique_id(void* out_id_bytes);     /* rank 0; broadcast by the host side */
+int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_bytes, int periodic_x);
+int xlbhip_comm_destroy(xlbhip_ctx* ctx);
+/* fill the ghost planes of f from the neighbours (blocking w.r.t. the compute stream order) */
+int xlbhip_halo_exchange(xlbhip_ctx* ctx, int lattice, xlbhip_field* f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XLBHIP_H */

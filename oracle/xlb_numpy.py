@@ -1,0 +1,473 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+NumPy restatement of the reference's per-timestep LBM hot path (the JAX branches
+of hsalehipour/XLB, which are the parity target).  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
+module, and only as the checker.  The product (`xlb_amd`) never imports it.
+
+Pinning status
+--------------
+* The reference ships NO golden vectors.  Its own tests hold seven closed-form
+  known-answer properties for this path (equilibrium, macroscopic, BGK, stream,
+  masker, EquilibriumBC, FullwayBB); `tests/test_oracle_reference_pins.py` checks
+  this oracle against every one of them.
+* KBC, HalfwayBounceBackBC, `missing_mask` contents and the composed multi-step
+  stepper are NOT pinned by any reference test or fixture: for those the status
+  is **parity unpinned by the reference**; they are cross-checked three ways
+  (this file <-> oracle/lbm_ref.c <-> HIP) plus physics invariants.
+* The reference itself cannot be imported here (it hard-imports `jax` and
+  `warp`, neither installed) so no reference-generated vectors exist.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference checkout).  Arithmetic order is fixed and explicit (sequential sums in
+direction order, no FMA) so that the C restatement and the HIP kernels can
+reproduce it bit for bit in the compute dtype.
+"""
+
+import itertools
+
+import numpy as np
+
+BC_NONE = 0  # xlb/cell_type.py:9
+
+# implementation_step values, xlb/operator/boundary_condition/boundary_condition.py:26-30
+STEP_COLLISION = 1
+STEP_STREAMING = 2
+
+KIND_EQUILIBRIUM = "equilibrium"
+KIND_HALFWAY_BB = "halfway_bounce_back"
+KIND_FULLWAY_BB = "fullway_bounce_back"
+KIND_DO_NOTHING = "do_nothing"
+
+
+# ----------------------------------------------------------------------------
+# Lattices
+# ----------------------------------------------------------------------------
+class Lattice:
+    """Lattice tables, re-derived with the constructions of
+    xlb/velocity_set/d2q9.py:18-21, d3q19.py:19-27, d3q27.py:19-29 and
+    xlb/velocity_set/velocity_set.py:63-83,139-253."""
+
+    def __init__(self, name):
+        name = name.upper()
+        if name == "D2Q9":
+            cx = [0, 0, 0, 1, -1, 1, -1, 1, -1]
+            cy = [0, 1, -1, 0, 1, -1, 0, 1, -1]
+            c = np.array(tuple(zip(cx, cy))).T
+            w = np.array([4 / 9, 1 / 9, 1 / 9, 1 / 9, 1 / 36, 1 / 36, 1 / 9, 1 / 36, 1 / 36])
+            d, q = 2, 9
+        elif name == "D3Q19":
+            c = np.array([ci for ci in itertools.product([0, -1, 1], repeat=3) if np.sum(np.abs(ci)) <= 2]).T
+            d, q = 3, 19
+            w = np.zeros(q)
+            n1 = np.sum(np.abs(c), axis=0)
+            w[n1 == 0] = 1.0 / 3.0
+            w[n1 == 1] = 1.0 / 18.0
+            w[n1 == 2] = 1.0 / 36.0
+        elif name == "D3Q27":
+            c = np.array(list(itertools.product([0, -1, 1], repeat=3))).T
+            d, q = 3, 27
+            w = np.zeros(q)
+            n1 = np.sum(np.abs(c), axis=0)
+            w[n1 == 0] = 8.0 / 27.0
+            w[n1 == 1] = 2.0 / 27.0
+            w[n1 == 2] = 1.0 / 54.0
+            w[n1 == 3] = 1.0 / 216.0
+        else:
+            raise ValueError(name)
+        self.name, self.d, self.q = name, d, q
+        self.c = c.astype(np.int64)  # (d, q)
+        self.w = w.astype(np.float64)
+        ct = self.c.T.tolist()
+        # velocity_set.py:182-195
+        self.opp = np.array([ct.index((-self.c.T[i]).tolist()) for i in range(q)])
+        # velocity_set.py:155-180: cc[:, k] = c_a * c_b for a <= b
+        nt = d * (d + 1) // 2
+        cc = np.zeros((q, nt))
+        k = 0
+        for a in range(d):
+            for b in range(a, d):
+                cc[:, k] = self.c[a] * self.c[b]
+                k += 1
+        self.cc = cc
+        self.right = np.nonzero(self.c[0] == 1)[0]  # velocity_set.py:214-224
+        self.left = np.nonzero(self.c[0] == -1)[0]  # velocity_set.py:226-236
+        self.main = np.nonzero(np.sum(np.abs(self.c), axis=0) == 1)[0]
+        self.center = int(np.nonzero(np.all(self.c == 0, axis=0))[0][0])
+
+
+def compute_dtype(policy):
+    """xlb/precision_policy.py:72-85"""
+    return {"FP64FP64": np.float64, "FP64FP32": np.float64, "FP64FP16": np.float64, "FP32FP32": np.float32, "FP32FP16": np.float32}[policy]
+
+
+def store_dtype(policy):
+    """xlb/precision_policy.py:87-100"""
+    return {"FP64FP64": np.float64, "FP64FP32": np.float32, "FP64FP16": np.float16, "FP32FP32": np.float32, "FP32FP16": np.float16}[policy]
+
+
+# ----------------------------------------------------------------------------
+# Grid helper
+# ----------------------------------------------------------------------------
+def bounding_box_indices(shape, remove_edges=False):
+    """xlb/grid/grid.py:135-191 (verbatim semantics, np.indices based)."""
+    origin = np.array([0, 0, 0])
+    bounds = np.array(shape)
+    if remove_edges:
+        origin = origin + 1
+        bounds = bounds - 1
+    sx = slice(origin[0], bounds[0])
+    sy = slice(origin[1], bounds[1])
+    dim = len(bounds)
+    grid = np.indices(shape)
+    if dim == 2:
+        nx, ny = shape
+        box = {"bottom": grid[:, sx, 0], "top": grid[:, sx, ny - 1], "left": grid[:, 0, sy], "right": grid[:, nx - 1, sy]}
+    else:
+        nx, ny, nz = shape
+        sz = slice(origin[2], bounds[2])
+        box = {
+            "bottom": grid[:, sx, sy, 0].reshape(3, -1),
+            "top": grid[:, sx, sy, nz - 1].reshape(3, -1),
+            "left": grid[:, 0, sy, sz].reshape(3, -1),
+            "right": grid[:, nx - 1, sy, sz].reshape(3, -1),
+            "front": grid[:, sx, 0, sz].reshape(3, -1),
+            "back": grid[:, sx, ny - 1, sz].reshape(3, -1),
+        }
+    return {k: v.tolist() for k, v in box.items()}
+
+
+# ----------------------------------------------------------------------------
+# Operators (whole field, compute dtype T = f.dtype)
+# ----------------------------------------------------------------------------
+def stream(f, lat):
+    """Pull streaming, periodic: out[l, x] = f[l, x - c_l].
+    xlb/operator/stream/stream.py:29-62 (vmap of jnp.roll with shift c_l)."""
+    out = np.empty_like(f)
+    axes = tuple(range(lat.d))
+    for l in range(lat.q):
+        out[l] = np.roll(f[l], tuple(int(s) for s in lat.c[:, l]), axis=axes)
+    return out
+
+
+def zero_moment(f):
+    """rho = sum_l f_l, sequential in l. xlb/operator/macroscopic/zero_moment.py:14-17"""
+    rho = f[0].copy()
+    for l in range(1, f.shape[0]):
+        rho = rho + f[l]
+    return rho[None]
+
+
+def first_moment(f, rho, lat):
+    """u_d = (sum_l c[d,l] f_l) / rho. xlb/operator/macroscopic/first_moment.py:14-18"""
+    T = f.dtype.type
+    u = np.zeros((lat.d,) + f.shape[1:], dtype=f.dtype)
+    for d in range(lat.d):
+        acc = np.zeros(f.shape[1:], dtype=f.dtype)
+        for l in range(lat.q):
+            cl = int(lat.c[d, l])
+            if cl == 1:
+                acc = acc + f[l]
+            elif cl == -1:
+                acc = acc - f[l]
+        u[d] = acc / rho[0]
+    del T
+    return u
+
+
+def macroscopic(f, lat):
+    """xlb/operator/macroscopic/macroscopic.py:21-26"""
+    rho = zero_moment(f)
+    u = first_moment(f, rho, lat)
+    return rho, u
+
+
+def second_moment(fneq, lat):
+    """Pi_k = sum_l cc[l,k] fneq_l. xlb/operator/macroscopic/second_moment.py:35-55"""
+    nt = lat.cc.shape[1]
+    pi = np.zeros((nt,) + fneq.shape[1:], dtype=fneq.dtype)
+    for k in range(nt):
+        acc = np.zeros(fneq.shape[1:], dtype=fneq.dtype)
+        for l in range(lat.q):
+            v = int(lat.cc[l, k])
+            if v == 1:
+                acc = acc + fneq[l]
+            elif v == -1:
+                acc = acc - fneq[l]
+        pi[k] = acc
+    return pi
+
+
+def equilibrium(rho, u, lat, T):
+    """feq_l = rho * w_l * (1 + cu (1 + 0.5 cu) - usqr), cu = 3 c_l.u, usqr = 1.5 u.u
+    xlb/operator/equilibrium/quadratic_equilibrium.py:23-30"""
+    rho = np.asarray(rho, dtype=T)
+    u = np.asarray(u, dtype=T)
+    w = lat.w.astype(T)
+    usq = u[0] * u[0]
+    for d in range(1, lat.d):
+        usq = usq + u[d] * u[d]
+    usqr = T(1.5) * usq
+    feq = np.empty((lat.q,) + u.shape[1:], dtype=T)
+    for l in range(lat.q):
+        dot = np.zeros(u.shape[1:], dtype=T)
+        for d in range(lat.d):
+            cl = int(lat.c[d, l])
+            if cl == 1:
+                dot = dot + u[d]
+            elif cl == -1:
+                dot = dot - u[d]
+        cu = T(3.0) * dot
+        feq[l] = (rho[0] * w[l]) * ((T(1.0) + cu * (T(1.0) + T(0.5) * cu)) - usqr)
+    return feq
+
+
+def bgk(f, feq, omega):
+    """fout = f - omega (f - feq). xlb/operator/collision/bgk.py:27-32"""
+    T = f.dtype.type
+    fneq = f - feq
+    return f - T(omega) * fneq
+
+
+def _shear_d3q27(pi):
+    """xlb/operator/collision/kbc.py:96-145"""
+    T = pi.dtype.type
+    nxz = pi[0] - pi[5]
+    nyz = pi[3] - pi[5]
+    s = {}
+    s[9] = s[18] = (T(2.0) * nxz - nyz) / T(6.0)
+    s[3] = s[6] = (-nxz + T(2.0) * nyz) / T(6.0)
+    s[1] = s[2] = (-nxz - nyz) / T(6.0)
+    s[12] = s[24] = pi[1] / T(4.0)
+    s[21] = s[15] = -pi[1] / T(4.0)
+    s[10] = s[20] = pi[2] / T(4.0)
+    s[19] = s[11] = -pi[2] / T(4.0)
+    s[8] = s[4] = pi[4] / T(4.0)
+    s[7] = s[5] = -pi[4] / T(4.0)
+    return s
+
+
+def _shear_d2q9(pi):
+    """xlb/operator/collision/kbc.py:147-174 followed by the /4 of kbc.py:61"""
+    T = pi.dtype.type
+    n = pi[0] - pi[2]
+    s = {}
+    s[3] = s[6] = n
+    s[2] = s[1] = -n
+    s[8] = s[7] = pi[1]
+    s[4] = s[5] = -pi[1]
+    return {k: v / T(4.0) for k, v in s.items()}
+
+
+def kbc(f, feq, omega, lat):
+    """Entropic KBC collision. xlb/operator/collision/kbc.py:40-94"""
+    T = f.dtype.type
+    fneq = f - feq
+    pi = second_moment(fneq, lat)
+    if lat.name == "D3Q27":
+        sd = _shear_d3q27(pi)
+    elif lat.name == "D2Q9":
+        sd = _shear_d2q9(pi)
+    else:
+        raise NotImplementedError("Velocity set not supported: " + lat.name)  # kbc.py:65-66
+    delta_s = np.zeros_like(fneq)
+    for k, v in sd.items():
+        delta_s[k] = v
+    beta = T(0.5) * T(omega)
+    inv_beta = T(1.0) / beta
+    delta_h = fneq - delta_s
+    temp = delta_h / feq
+    sp1 = temp[0] * delta_s[0]
+    sp2 = temp[0] * delta_h[0]
+    for l in range(1, lat.q):
+        sp1 = sp1 + temp[l] * delta_s[l]
+        sp2 = sp2 + temp[l] * delta_h[l]
+    gamma = inv_beta - ((T(2.0) - inv_beta) * sp1) / (T(1e-32) + sp2)
+    return f - beta * (T(2.0) * delta_s + gamma[None] * delta_h)
+
+
+# ----------------------------------------------------------------------------
+# Boundary conditions
+# ----------------------------------------------------------------------------
+class BC:
+    """Plain descriptor of an in-scope boundary condition.
+
+    id semantics follow xlb/operator/boundary_condition/boundary_condition.py:68 and
+    boundary_condition_registry.py:16-27: ids are handed out by the caller here
+    (the oracle has no process-global registry)."""
+
+    def __init__(self, kind, bc_id, indices, rho=None, u=None, u_wall=None):
+        self.kind = kind
+        self.id = int(bc_id)
+        self.indices = None if indices is None else np.asarray(indices, dtype=np.int64)
+        self.rho = rho
+        self.u = u
+        self.u_wall = u_wall
+        self.step = STEP_COLLISION if kind == KIND_FULLWAY_BB else STEP_STREAMING
+        # bc_halfway_bounce_back.py:60 sets needs_padding; others keep the base False
+        self.needs_padding = kind == KIND_HALFWAY_BB
+
+    def pad_indices(self, lat):
+        """boundary_condition.py:123-136"""
+        if self.needs_padding:
+            padded = self.indices[:, :, None] + lat.c[:, None, :]
+            return np.unique(padded.reshape(lat.d, -1), axis=1)
+        return self.indices
+
+
+def _bcast(mask, q):
+    return np.broadcast_to(mask, (q,) + mask.shape[1:])
+
+
+def apply_bc(bc, f_pre, f_post, bc_mask, missing_mask, lat, policy):
+    """Dispatch on kind; JAX branches of bc_equilibrium.py:72-80,
+    bc_halfway_bounce_back.py:116-134, bc_fullway_bounce_back.py:50-56,
+    bc_do_nothing.py:50-54."""
+    T = f_post.dtype.type
+    boundary = bc_mask == bc.id  # (1, ...)
+    if bc.kind == KIND_EQUILIBRIUM:
+        feq = equilibrium(np.array([bc.rho], dtype=T), np.array(bc.u, dtype=T), lat, T)  # (q,)
+        feq = feq.reshape((lat.q,) + (1,) * lat.d)
+        return np.where(boundary, feq, f_post)
+    if bc.kind == KIND_HALFWAY_BB:
+        mw = T(0.0)
+        if bc.u_wall is not None:
+            S = store_dtype(policy)
+            uw = np.asarray(bc.u_wall, dtype=np.float64).astype(S)
+            w = lat.w.astype(T)
+            comp = np.zeros(lat.q, dtype=T)
+            for l in range(lat.q):
+                dot = S(0)
+                for d in range(lat.d):
+                    dot = S(dot + S(int(lat.c[d, l])) * uw[d])
+                comp[l] = T(6.0) * (w[l] * T(dot))
+            mw = comp.reshape((lat.q,) + (1,) * lat.d)
+        cond = np.logical_and(missing_mask.astype(bool), _bcast(boundary, lat.q))
+        return np.where(cond, f_pre[lat.opp] + mw, f_post)
+    if bc.kind == KIND_FULLWAY_BB:
+        return np.where(_bcast(boundary, lat.q), f_pre[lat.opp], f_post)
+    if bc.kind == KIND_DO_NOTHING:
+        return np.where(_bcast(boundary, lat.q), f_pre, f_post)
+    raise ValueError(bc.kind)
+
+
+def are_indices_in_interior(indices, shape):
+    """xlb/operator/boundary_masker/indices_boundary_masker.py:51-62"""
+    d = len(shape)
+    sh = np.array(shape)
+    return np.all((indices[:d] > 0) & (indices[:d] < sh[:d, None] - 1), axis=0)
+
+
+def build_masks(shape, lat, bcs, missing_in=None, bc_mask_in=None):
+    """JAX masker, xlb/operator/boundary_masker/indices_boundary_masker.py:73-143,
+    with nDevices == 1 (pad 1 in every direction).
+
+    Returns bc_mask (1, *shape) uint8 and missing_mask (q, *shape) bool."""
+    dim = len(shape)
+    bc_mask = np.zeros((1,) + tuple(shape), dtype=np.uint8) if bc_mask_in is None else bc_mask_in.copy()
+    missing = np.zeros((lat.q,) + tuple(shape), dtype=bool) if missing_in is None else missing_in.astype(bool)
+    pad = ((1, 1),) * dim
+    bm = np.pad(bc_mask[0], pad, constant_values=0)
+    mm = np.pad(missing, ((0, 0),) + pad, constant_values=True)
+    shift = np.ones((dim, 1), dtype=np.int64)
+    for bc in bcs:
+        idx = bc.indices
+        if np.any(are_indices_in_interior(idx, shape)):
+            solid = idx + shift
+            mm[(slice(None),) + tuple(solid)] = True
+            tagged = bc.pad_indices(lat) + shift
+        else:
+            tagged = idx + shift
+        bm[tuple(tagged)] = bc.id
+    mm = stream(mm, lat)
+    crop = (slice(1, -1),) * dim
+    bc_mask[0] = bm[crop]
+    missing = mm[(slice(None),) + crop]
+    return bc_mask, np.ascontiguousarray(missing)
+
+
+# ----------------------------------------------------------------------------
+# The step
+# ----------------------------------------------------------------------------
+def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collision="BGK"):
+    """One pull-scheme LBM step -> f_1 (store dtype).
+    xlb/operator/stepper/nse_stepper.py:237-282."""
+    T = compute_dtype(policy)
+    S = store_dtype(policy)
+    F0 = f_0.astype(T)
+    post_stream = stream(F0, lat)
+    for bc in bcs:
+        if bc.step == STEP_STREAMING:
+            post_stream = apply_bc(bc, F0, post_stream, bc_mask, missing_mask, lat, policy)
+    rho, u = macroscopic(post_stream, lat)
+    feq = equilibrium(rho, u, lat, T)
+    if collision == "BGK":
+        post_coll = bgk(post_stream, feq, omega)
+    elif collision == "KBC":
+        post_coll = kbc(post_stream, feq, omega, lat)
+    else:
+        raise ValueError(collision)
+    for bc in bcs:
+        if bc.step == STEP_COLLISION:
+            post_coll = apply_bc(bc, post_stream, post_coll, bc_mask, missing_mask, lat, policy)
+    return post_coll.astype(S)
+
+
+def run(f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, policy="FP32FP32", collision="BGK"):
+    """The caller's loop: step then swap (examples/cfd/lid_driven_cavity_2d.py:64-67)."""
+    f = f_0
+    for _ in range(n_steps):
+        f = step(f, bc_mask, missing_mask, bcs, omega, lat, policy, collision)
+    return f
+
+
+def initialize_eq(shape, lat, policy="FP32FP32"):
+    """f = feq(rho=1, u=0) in compute dtype, stored. xlb/helper/initializers.py:25-72"""
+    T = compute_dtype(policy)
+    rho = np.ones((1,) + tuple(shape), dtype=T)
+    u = np.zeros((lat.d,) + tuple(shape), dtype=T)
+    return equilibrium(rho, u, lat, T).astype(store_dtype(policy))
+
+
+# ----------------------------------------------------------------------------
+# Drivers (what the reference's example scripts set up)
+# ----------------------------------------------------------------------------
+def cavity_2d(n, u_lid=0.05):
+    """examples/cfd/lid_driven_cavity_2d.py:43-55: lid constructed first (id 1),
+    walls second (id 2), listed [walls, lid]."""
+    lat = Lattice("D2Q9")
+    shape = (n, n)
+    box = bounding_box_indices(shape)
+    box_ne = bounding_box_indices(shape, remove_edges=True)
+    lid = box_ne["top"]
+    walls = [box["bottom"][i] + box["left"][i] + box["right"][i] for i in range(2)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    bc_top = BC(KIND_EQUILIBRIUM, 1, lid, rho=1.0, u=(u_lid, 0.0))
+    bc_walls = BC(KIND_HALFWAY_BB, 2, walls)
+    return lat, shape, [bc_walls, bc_top]
+
+
+def cavity_3d(n, walls_kind=KIND_FULLWAY_BB, u_lid=0.02, lattice="D3Q19"):
+    """examples/performance/mlups_3d.py:193-204: lid id 1 (EquilibriumBC), walls id 2,
+    listed [lid, walls]."""
+    lat = Lattice(lattice)
+    shape = (n, n, n) if np.isscalar(n) else tuple(n)
+    box = bounding_box_indices(shape)
+    box_ne = bounding_box_indices(shape, remove_edges=True)
+    lid = box_ne["top"]
+    walls = [box["bottom"][i] + box["left"][i] + box["right"][i] + box["front"][i] + box["back"][i] for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    bc_lid = BC(KIND_EQUILIBRIUM, 1, lid, rho=1.0, u=(u_lid, 0.0, 0.0))
+    bc_walls = BC(walls_kind, 2, walls)
+    return lat, shape, [bc_lid, bc_walls]
+
+
+def perturbed_init(shape, lat, policy="FP32FP32", seed=0, amp_rho=0.01, amp_u=0.01):
+    """Synthetic non-equilibrium-free but non-trivial start:
+    f = feq(1 + amp*xi, amp*eta), xi, eta ~ U(-1, 1), default_rng(seed)."""
+    T = compute_dtype(policy)
+    rng = np.random.default_rng(seed)
+    rho = (1.0 + amp_rho * rng.uniform(-1, 1, size=(1,) + tuple(shape))).astype(T)
+    u = (amp_u * rng.uniform(-1, 1, size=(lat.d,) + tuple(shape))).astype(T)
+    return equilibrium(rho, u, lat, T).astype(store_dtype(policy))

@@ -1,0 +1,237 @@
+"""Parity of the fused HIP stepper (through the C ABI) with the oracle and with the committed
+golden fixtures.  fp32/fp64 results are expected to be BIT-IDENTICAL to the oracle (same
+operation order, no FMA contraction); the asserted bar is the north-star tolerance
+(|delta rho|, |delta u| <= 1e-6 in fp32) plus bit-exact integer masks."""
+
+import numpy as np
+import pytest
+
+from oracle import xlb_numpy as orc
+from xlb_amd import ComputeBackend, PrecisionPolicy
+from xlb_amd.default_config import get_context
+from xlb_amd.grid import grid_factory
+from xlb_amd.operator.boundary_condition import FullwayBounceBackBC, HalfwayBounceBackBC, EquilibriumBC, DoNothingBC
+from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
+
+from _util import golden, hip_cavity_2d, hip_cavity_3d, hip_macroscopic, init_hip, max_ulp_diff, remap_ids
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6  # BASELINE.json north_star: rho/u within 1e-6 in fp32
+
+
+def run_reference_loop(stepper, f_0, f_1, bc_mask, missing_mask, omega, n, t0=0):
+    """The caller loop of the reference drivers (lid_driven_cavity_2d.py:64-67)."""
+    for i in range(n):
+        f_0, f_1 = stepper(f_0, f_1, bc_mask, missing_mask, omega, t0 + i)
+        f_0, f_1 = f_1, f_0
+    return f_0, f_1
+
+
+@pytest.mark.parametrize("n", [16, 128])
+def test_config1_d2q9_cavity_vs_golden(n):
+    """BASELINE config 1: D2Q9 BGK lid-driven cavity 128x128 fp32 (and its 16x16 twin)."""
+    g = golden(f"d2q9_cavity_{n}")
+    grid, bcs, lat, obcs = hip_cavity_2d(n)
+    vs, pp = bcs[0].velocity_set, bcs[0].precision_policy
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type="BGK")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    # masks: bit-exact (golden ids are lid=1, walls=2; this process's ids may differ)
+    ids = {bcs[1].id: 1, bcs[0].id: 2}
+    assert np.array_equal(remap_ids(bc_mask.numpy(), ids), g["bc_mask"])
+    assert np.array_equal(missing_mask.numpy(), g["missing_mask"])
+    omega = float(g["omega"])
+    done = 0
+    for s in g["steps"]:
+        s = int(s)
+        if s - done <= 10:
+            f_0, f_1 = run_reference_loop(stepper, f_0, f_1, bc_mask, missing_mask, omega, s - done, done)
+        else:
+            f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, s - done, first_timestep=done)
+        done = s
+        rho, u = hip_macroscopic(f_0, grid, vs, pp)
+        # boundary ring stripped as the reference post-processing does (lid_driven_cavity_2d.py:89-90) ...
+        assert np.abs(rho - g[f"rho_{s}"])[:, 1:-1, 1:-1].max() <= TOL
+        assert np.abs(u - g[f"u_{s}"])[:, 1:-1, 1:-1].max() <= TOL
+        # ... and the whole field too, which is stronger
+        assert np.abs(rho - g[f"rho_{s}"]).max() <= TOL and np.abs(u - g[f"u_{s}"]).max() <= TOL
+        assert max_ulp_diff(rho, g[f"rho_{s}"]) == 0 and max_ulp_diff(u, g[f"u_{s}"]) == 0
+        if n <= 16:
+            assert np.array_equal(f_0.numpy(), g[f"f_{s}"])
+
+
+@pytest.mark.parametrize("omega", [1.0, 1.7])
+def test_config2_twin_d3q19_periodic_vs_golden(omega):
+    """BASELINE config 2 twin: D3Q19 BGK periodic, perturbed init (16^3 golden)."""
+    g = golden("d3q19_periodic_16")
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    shape = (16, 16, 16)
+    grid = grid_factory(shape)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[], collision_type="BGK")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_0.assign(orc.perturbed_init(shape, lat, seed=int(g["seed"])))
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, int(g["steps"]))
+    out = f_0.numpy()
+    assert np.abs(out - g[f"f_omega{omega}"]).max() <= TOL
+    assert np.array_equal(out, g[f"f_omega{omega}"])
+
+
+@pytest.mark.parametrize("walls_cls,tag", [(FullwayBounceBackBC, "fullway"), (HalfwayBounceBackBC, "halfway")])
+def test_config3_twin_d3q19_cavity_vs_golden(walls_cls, tag):
+    """BASELINE config 3 twin: D3Q19 BGK cavity, both wall treatments (16^3 golden)."""
+    g = golden("d3q19_cavity_16")
+    grid, bcs, lat, obcs = hip_cavity_3d((16, 16, 16), walls_cls)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type="BGK")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert np.array_equal(remap_ids(bc_mask.numpy(), {bcs[0].id: 1, bcs[1].id: 2}), g["bc_mask"])
+    assert np.array_equal(np.packbits(missing_mask.numpy(), axis=0), g["missing_mask"])
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, int(g["steps"]))
+    out = f_0.numpy()
+    assert np.abs(out - g[f"f_{tag}"]).max() <= TOL
+    assert np.array_equal(out, g[f"f_{tag}"])
+
+
+@pytest.mark.parametrize("policy", ["FP64FP32", "FP32FP32", "FP64FP64"])
+def test_config5_twin_d3q27_kbc_vs_golden(policy):
+    """BASELINE config 5 twin: D3Q27 KBC, mixed precision (12^3 golden)."""
+    g = golden("d3q27_kbc_12")
+    vs, pp = init_hip("D3Q27", policy)
+    lat = orc.Lattice("D3Q27")
+    shape = (12, 12, 12)
+    grid = grid_factory(shape)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[], collision_type="KBC")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_0.assign(orc.perturbed_init(shape, lat, policy, seed=0))
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, float(g["omega"]), int(g["steps"]))
+    out = f_0.numpy()
+    tol = TOL if policy != "FP64FP64" else 1e-12
+    assert np.abs(out.astype(np.float64) - g[f"f_{policy}"]).max() <= tol
+    assert np.array_equal(out, g[f"f_{policy}"])
+
+
+def test_d2q9_kbc_cavity_vs_golden():
+    g = golden("d2q9_kbc_cavity_16")
+    grid, bcs, lat, obcs = hip_cavity_2d(16)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type="KBC")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, float(g["omega"]), int(g["steps"]))
+    assert np.array_equal(f_0.numpy(), g["f"])
+
+
+CASES = [
+    # lattice, shape, policy, collision, omega, steps
+    ("D3Q19", (32, 32, 32), "FP32FP32", "BGK", 1.7, 8),
+    ("D3Q19", (6, 10, 18), "FP32FP32", "BGK", 1.2, 6),  # nz % 4 != 0 -> one cell per thread
+    ("D3Q19", (5, 7, 4), "FP32FP32", "BGK", 1.0, 5),  # nz == VEC: both row ends in one thread
+    ("D3Q19", (3, 3, 8), "FP64FP64", "BGK", 1.9, 5),
+    ("D3Q19", (8, 8, 8), "FP32FP16", "BGK", 1.1, 5),
+    ("D3Q19", (8, 8, 8), "FP64FP16", "BGK", 1.1, 5),
+    ("D3Q19", (8, 12, 16), "FP64FP32", "BGK", 1.5, 5),
+    ("D3Q27", (8, 8, 12), "FP32FP32", "BGK", 1.6, 5),
+    ("D3Q27", (8, 8, 12), "FP32FP32", "KBC", 1.95, 5),
+    ("D3Q27", (4, 6, 10), "FP64FP32", "KBC", 1.8, 5),
+    ("D2Q9", (24, 36), "FP32FP32", "BGK", 1.4, 10),
+    ("D2Q9", (20, 30), "FP64FP64", "KBC", 1.9, 10),
+    ("D2Q9", (1, 8), "FP32FP32", "BGK", 1.0, 3),
+]
+
+
+@pytest.mark.parametrize("lattice,shape,policy,collision,omega,steps", CASES)
+def test_periodic_step_vs_oracle(lattice, shape, policy, collision, omega, steps):
+    vs, pp = init_hip(lattice, policy)
+    lat = orc.Lattice(lattice)
+    grid = grid_factory(shape)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[], collision_type=collision)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_np = orc.perturbed_init(shape, lat, policy, seed=7, amp_rho=0.02, amp_u=0.03)
+    f_0.assign(f_np)
+    f_0, f_1 = run_reference_loop(stepper, f_0, f_1, bc_mask, missing_mask, omega, steps)
+    bm = np.zeros((1,) + shape, np.uint8)
+    mm = np.zeros((lat.q,) + shape, bool)
+    exp = orc.run(f_np, bm, mm, [], omega, lat, steps, policy, collision)
+    out = f_0.numpy()
+    assert out.dtype == exp.dtype
+    tol = {"FP32FP32": TOL, "FP64FP32": TOL, "FP64FP64": 1e-12, "FP32FP16": 2e-3, "FP64FP16": 2e-3}[policy]
+    assert np.abs(out.astype(np.float64) - exp.astype(np.float64)).max() <= tol
+    assert np.array_equal(out, exp), f"not bit-exact: max ulp {max_ulp_diff(out, exp)}"
+
+
+@pytest.mark.parametrize("vec", [1, 4])
+@pytest.mark.parametrize("shape", [(12, 16, 20), (16, 16, 16)])
+def test_all_bc_kinds_in_one_step_vs_oracle(shape, vec):
+    """Every in-scope BC kind at once (incl. a moving halfway wall and an interior solid
+    sphere), with list order != id order, on the vectorised and the scalar kernel."""
+    vs, pp = init_hip("D3Q19")
+    get_context().set_option("vec", vec)
+    try:
+        lat = orc.Lattice("D3Q19")
+        grid = grid_factory(shape)
+        box = grid.bounding_box_indices()
+        box_ne = grid.bounding_box_indices(remove_edges=True)
+        n = shape[0]
+        g3 = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+        sph = [a.tolist() for a in np.where(sum((g - s // 2) ** 2 for g, s in zip(g3, shape)) < (n // 4) ** 2)]
+        b_lid = EquilibriumBC(rho=1.0, u=(0.02, 0.0, 0.0), indices=box_ne["top"])
+        b_mov = HalfwayBounceBackBC(indices=box_ne["bottom"], prescribed_value=(0.0, 0.01, 0.0))
+        b_fw = FullwayBounceBackBC(indices=box_ne["left"])
+        b_dn = DoNothingBC(indices=box_ne["right"])
+        b_sph = HalfwayBounceBackBC(indices=sph)
+        b_hw = HalfwayBounceBackBC(indices=box_ne["front"])
+        bcs = [b_sph, b_fw, b_lid, b_dn, b_mov, b_hw]
+        obcs = [
+            orc.BC(orc.KIND_HALFWAY_BB, b_sph.id, sph),
+            orc.BC(orc.KIND_FULLWAY_BB, b_fw.id, box_ne["left"]),
+            orc.BC(orc.KIND_EQUILIBRIUM, b_lid.id, box_ne["top"], rho=1.0, u=(0.02, 0.0, 0.0)),
+            orc.BC(orc.KIND_DO_NOTHING, b_dn.id, box_ne["right"]),
+            orc.BC(orc.KIND_HALFWAY_BB, b_mov.id, box_ne["bottom"], u_wall=(0.0, 0.01, 0.0)),
+            orc.BC(orc.KIND_HALFWAY_BB, b_hw.id, box_ne["front"]),
+        ]
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type="BGK")
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+        f_np = orc.perturbed_init(shape, lat, seed=11)
+        f_0.assign(f_np)
+        steps = 7
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, steps)
+        exp = orc.run(f_np, o_bm, o_mm, obcs, 1.3, lat, steps)
+        out = f_0.numpy()
+        assert np.abs(out - exp).max() <= TOL
+        assert np.array_equal(out, exp), f"not bit-exact: max ulp {max_ulp_diff(out, exp)}"
+    finally:
+        get_context().set_option("vec", 0)
+
+
+@pytest.mark.parametrize("walls_cls", [FullwayBounceBackBC, HalfwayBounceBackBC])
+def test_ghost_plane_protocol_single_rank(walls_cls):
+    """Fields with ghost x-planes + self ring exchange (the slab protocol on one rank) give the
+    same bits as the plain periodic kernel, with and without interior/edge splitting."""
+    results = []
+    for cfg in (None, {"halo": True}):
+        grid, bcs, lat, obcs = hip_cavity_3d((10, 8, 16), walls_cls, backend_config=cfg)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        f_0.assign(orc.perturbed_init((10, 8, 16), lat, seed=3))
+        for overlap in (1, 0):
+            get_context().set_option("overlap", overlap)
+            f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.4, 3)
+        get_context().set_option("overlap", 1)
+        results.append(f_0.numpy())
+    assert np.array_equal(results[0], results[1])
+
+
+def test_stepper_argument_errors():
+    vs, pp = init_hip("D3Q19")
+    grid = grid_factory((8, 8, 8))
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    with pytest.raises(Exception, match="different fields"):
+        stepper(f_0, f_0, bc_mask, missing_mask, 1.0, 0)
+    wrong = grid.create_field(9)
+    with pytest.raises(Exception, match="cardinality"):
+        stepper(f_0, wrong, bc_mask, missing_mask, 1.0, 0)
+    with pytest.raises(AssertionError):
+        IncompressibleNavierStokesStepper(grid=grid, streaming_scheme="push")
+    with pytest.raises(NotImplementedError):
+        IncompressibleNavierStokesStepper(grid=grid, collision_type="KBC")  # D3Q19 has no KBC (kbc.py:65-66)

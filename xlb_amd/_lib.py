@@ -1,0 +1,332 @@
+"""ctypes binding of libxlbhip.so (include/xlbhip.h) and thin RAII wrappers.
+
+This is the stub a reference maintainer would add for a ``ComputeBackend.HIP`` (see
+INTEGRATION.md): every ``hip_implementation`` method of the operators calls one function of
+the C ABI through the objects defined here.  There is NO fallback: if the shared library is
+missing or a call fails, an exception is raised.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libxlbhip.so")
+
+# element types (include/xlbhip.h)
+F64, F32, F16, U8, BOOL, MISSING = 0, 1, 2, 3, 4, 5
+D2Q9, D3Q19, D3Q27 = 0, 1, 2
+BGK, KBC = 0, 1
+BC_EQUILIBRIUM, BC_HALFWAY_BB, BC_FULLWAY_BB, BC_DO_NOTHING = 1, 2, 3, 4
+UNIQUE_ID_BYTES = 128
+
+NP_OF_DTYPE = {F64: np.float64, F32: np.float32, F16: np.float16, U8: np.uint8, BOOL: np.bool_, MISSING: np.uint8}
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+class BcDesc(C.Structure):
+    _fields_ = [("id", C.c_int32), ("kind", C.c_int32), ("values", C.c_double * 27)]
+
+
+_p = C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+_i = C.c_int
+_i64 = C.c_int64
+_d = C.c_double
+
+# name -> argtypes ; every function returns int except xlbhip_last_error
+SIGNATURES = {
+    "xlbhip_create": [_i, _pp],
+    "xlbhip_destroy": [_p],
+    "xlbhip_sync": [_p],
+    "xlbhip_device_info": [_p, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
+    "xlbhip_set_option": [_p, C.c_char_p, _i64],
+    "xlbhip_get_option": [_p, C.c_char_p, C.POINTER(_i64)],
+    "xlbhip_lattice_info": [_i, C.POINTER(_i), C.POINTER(_i), _p, _p, _p, _p],
+    "xlbhip_field_create": [_p, _i, _i, _i, _i, _i, _i, _d, _pp],
+    "xlbhip_field_destroy": [_p],
+    "xlbhip_field_fill": [_p, _d],
+    "xlbhip_field_copy": [_p, _p],
+    "xlbhip_field_upload": [_p, _p, C.c_size_t],
+    "xlbhip_field_download": [_p, _p, C.c_size_t],
+    "xlbhip_field_info": [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                          C.POINTER(C.c_uint64), _pp],
+    "xlbhip_stream": [_p, _i, _p, _p],
+    "xlbhip_equilibrium": [_p, _i, _i, _p, _p, _p],
+    "xlbhip_macroscopic": [_p, _i, _i, _p, _p, _p],
+    "xlbhip_second_moment": [_p, _i, _i, _p, _p],
+    "xlbhip_collide": [_p, _i, _i, _i, _p, _p, _p, _d],
+    "xlbhip_apply_bc": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, _p],
+    "xlbhip_build_masks": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
+    "xlbhip_stepper_create": [_p, _i, _i, _i, _i, _i, C.POINTER(BcDesc), _pp],
+    "xlbhip_stepper_destroy": [_p],
+    "xlbhip_step": [_p, _p, _p, _p, _p, _d, _i64],
+    "xlbhip_run": [_p, _p, _p, _p, _p, _d, _i64, _i64],
+    "xlbhip_run_timed": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_float)],
+    "xlbhip_comm_unique_id": [_p],
+    "xlbhip_comm_init": [_p, _i, _i, _p, _i],
+    "xlbhip_comm_destroy": [_p],
+    "xlbhip_halo_exchange": [_p, _i, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load libxlbhip.so; fail loudly when it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipBackendError(
+            f"{LIB_PATH} not found: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "xlb_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.xlbhip_last_error.argtypes = []
+    lib.xlbhip_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HipBackendError(load().xlbhip_last_error().decode("utf-8", "replace"))
+
+
+def lattice_info(lattice_id):
+    lib = load()
+    d, q = _i(), _i()
+    c = np.zeros((3, 27), np.int32)
+    w = np.zeros(27, np.float64)
+    opp = np.zeros(27, np.int32)
+    cc = np.zeros((27, 6), np.int32)
+    cbuf = np.zeros(3 * 27, np.int32)
+    ccbuf = np.zeros(27 * 6, np.int32)
+    check(lib.xlbhip_lattice_info(lattice_id, C.byref(d), C.byref(q), cbuf.ctypes.data, w.ctypes.data, opp.ctypes.data, ccbuf.ctypes.data))
+    qq = q.value
+    c = cbuf[: 3 * qq].reshape(3, qq)
+    cc = ccbuf[: qq * 6].reshape(qq, 6)
+    return d.value, qq, c, w[:qq].copy(), opp[:qq].copy(), cc
+
+
+class Context:
+    """Device context: HIP device + compute/communication streams (xlbhip_create)."""
+
+    def __init__(self, device=0):
+        self._h = _p()
+        check(load().xlbhip_create(int(device), C.byref(self._h)))
+        self.device = int(device)
+        self.rank, self.n_ranks = 0, 1
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise HipBackendError("context already destroyed")
+        return self._h
+
+    def sync(self):
+        check(load().xlbhip_sync(self.handle))
+
+    def set_option(self, key, value):
+        check(load().xlbhip_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = _i64()
+        check(load().xlbhip_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = _i(), C.c_uint64()
+        check(load().xlbhip_device_info(self.handle, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value}
+
+    def comm_init(self, rank, n_ranks, id_bytes, periodic_x=True):
+        buf = C.create_string_buffer(bytes(id_bytes), UNIQUE_ID_BYTES) if id_bytes is not None else None
+        check(load().xlbhip_comm_init(self.handle, int(rank), int(n_ranks), buf, 1 if periodic_x else 0))
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def close(self):
+        if self._h:
+            load().xlbhip_destroy(self._h)
+            self._h = _p()
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(load().xlbhip_comm_unique_id(buf))
+    return buf.raw
+
+
+class Field:
+    """A device-resident field.  Host-visible shape is (cardinality, nx, ny[, nz]) C-order,
+    exactly the reference layout; the device layout is private."""
+
+    def __init__(self, ctx, cardinality, shape, dtype_code, halo=0, fill_value=0.0):
+        self.ctx = ctx
+        self.cardinality = int(cardinality)
+        self.grid_shape = tuple(int(s) for s in shape)
+        assert len(self.grid_shape) in (2, 3)
+        self.dtype_code = int(dtype_code)
+        self.halo = int(halo)
+        s3 = (1,) + self.grid_shape if len(self.grid_shape) == 2 else self.grid_shape
+        self._s3 = s3
+        self._h = _p()
+        check(load().xlbhip_field_create(ctx.handle, self.cardinality, s3[0], s3[1], s3[2], self.dtype_code, self.halo,
+                                         float(fill_value or 0.0), C.byref(self._h)))
+
+    # -- reference-like attributes
+    @property
+    def shape(self):
+        return (self.cardinality,) + self.grid_shape
+
+    @property
+    def dtype(self):
+        return np.dtype(NP_OF_DTYPE[self.dtype_code])
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise HipBackendError("field already destroyed")
+        return self._h
+
+    @property
+    def nbytes_host(self):
+        return int(np.prod(self.shape)) * self.dtype.itemsize
+
+    def numpy(self):
+        """Synchronous device -> host copy in the reference layout."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(load().xlbhip_field_download(self.handle, out.ctypes.data, out.nbytes))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def assign(self, array):
+        a = np.ascontiguousarray(np.asarray(array), dtype=self.dtype)
+        if a.shape != self.shape:
+            raise ValueError(f"shape {a.shape} does not match field shape {self.shape}")
+        check(load().xlbhip_field_upload(self.handle, a.ctypes.data, a.nbytes))
+        return self
+
+    def fill(self, value):
+        check(load().xlbhip_field_fill(self.handle, float(value)))
+        return self
+
+    def copy_from(self, other):
+        check(load().xlbhip_field_copy(self.handle, other.handle))
+        return self
+
+    def info(self):
+        card, nx, ny, nz, dt, halo = _i(), _i(), _i(), _i(), _i(), _i()
+        ps, ptr = C.c_uint64(), _p()
+        check(load().xlbhip_field_info(self.handle, C.byref(card), C.byref(nx), C.byref(ny), C.byref(nz), C.byref(dt), C.byref(halo),
+                                       C.byref(ps), C.byref(ptr)))
+        return {"cardinality": card.value, "nx": nx.value, "ny": ny.value, "nz": nz.value, "dtype": dt.value, "halo": halo.value,
+                "plane_stride": ps.value, "device_ptr": ptr.value}
+
+    def free(self):
+        if self._h:
+            load().xlbhip_field_destroy(self._h)
+            self._h = _p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return f"HipField(shape={self.shape}, dtype={self.dtype}, halo={self.halo})"
+
+
+def make_bc_desc(bc_id, kind, values):
+    d = BcDesc()
+    d.id = int(bc_id)
+    d.kind = int(kind)
+    v = np.zeros(27, np.float64)
+    if values is not None:
+        values = np.asarray(values, np.float64).ravel()
+        v[: values.size] = values
+    for i in range(27):
+        d.values[i] = v[i]
+    return d
+
+
+def _h(field):
+    return field.handle if field is not None else None
+
+
+class Stepper:
+    """Native stepper object (xlbhip_stepper_create)."""
+
+    def __init__(self, ctx, lattice_id, collision_id, compute_code, store_code, bc_descs):
+        self.ctx = ctx
+        n = len(bc_descs)
+        arr = (BcDesc * max(n, 1))(*bc_descs)
+        self._h = _p()
+        check(load().xlbhip_stepper_create(ctx.handle, lattice_id, collision_id, compute_code, store_code, n, arr, C.byref(self._h)))
+
+    def step(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
+        check(load().xlbhip_step(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
+
+    def run(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
+        check(load().xlbhip_run(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
+                                int(n_steps)))
+
+    def run_timed(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
+        ms = C.c_float()
+        check(load().xlbhip_run_timed(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
+                                      int(n_steps), C.byref(ms)))
+        return ms.value
+
+    def free(self):
+        if self._h:
+            load().xlbhip_stepper_destroy(self._h)
+            self._h = _p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def build_masks(ctx, lattice_id, bc_ids, tag_lists, solid_lists, global_shape3, x_offset, bc_mask, missing_mask):
+    """tag_lists / solid_lists: per BC an int32 (3, n) array (or None)."""
+    n = len(bc_ids)
+    ids = np.asarray(bc_ids, np.int32)
+    keep = []
+    tag_ptrs = (C.c_void_p * max(n, 1))()
+    sol_ptrs = (C.c_void_p * max(n, 1))()
+    tag_cnt = np.zeros(max(n, 1), np.int64)
+    sol_cnt = np.zeros(max(n, 1), np.int64)
+    for i in range(n):
+        t = np.ascontiguousarray(tag_lists[i], dtype=np.int32)
+        assert t.ndim == 2 and t.shape[0] == 3
+        keep.append(t)
+        tag_ptrs[i] = t.ctypes.data
+        tag_cnt[i] = t.shape[1]
+        s = solid_lists[i]
+        if s is not None and np.size(s) > 0:
+            s = np.ascontiguousarray(s, dtype=np.int32)
+            assert s.ndim == 2 and s.shape[0] == 3
+            keep.append(s)
+            sol_ptrs[i] = s.ctypes.data
+            sol_cnt[i] = s.shape[1]
+    gs = np.asarray(global_shape3, np.int32)
+    check(load().xlbhip_build_masks(ctx.handle, lattice_id, n, ids.ctypes.data, C.cast(tag_ptrs, C.c_void_p), tag_cnt.ctypes.data,
+                                    C.cast(sol_ptrs, C.c_void_p), sol_cnt.ctypes.data, gs.ctypes.data, int(x_offset), bc_mask.handle,
+                                    missing_mask.handle))
+    del keep

@@ -1,0 +1,192 @@
+// Per-cell LBM arithmetic shared by the fused stepper and the whole-field operators.
+//
+// Operation order is FIXED and matches oracle/xlb_numpy.py term by term (sequential
+// sums in direction order, the reference's association in feq and BGK); the library is
+// compiled with -ffp-contract=off so that fp32/fp64 results are bit-identical to the
+// oracle.  Reference formulas: quadratic_equilibrium.py:26-29, zero_moment.py:17,
+// first_moment.py:17, bgk.py:30-31, kbc.py:58-174, second_moment.py:55.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "../../include/xlbhip.h"
+#include "lattice.hpp"
+
+namespace xlb {
+
+// ---- storage <-> compute conversion (precision_policy.py:100-110; RNE like numpy) ----
+template <class T, class S>
+__device__ __forceinline__ T to_compute(S v) {
+  return static_cast<T>(v);
+}
+template <>
+__device__ __forceinline__ float to_compute<float, _Float16>(_Float16 v) {
+  return static_cast<float>(v);
+}
+template <class S, class T>
+__device__ __forceinline__ S to_store(T v) {
+  return static_cast<S>(v);
+}
+
+// ---- moments -------------------------------------------------------------------
+template <class L, class T>
+__device__ __forceinline__ void moments(const T (&f)[L::Q], T& rho, T (&u)[3]) {
+  T r = f[0];
+  static_for<L::Q - 1>([&](auto lc) {
+    constexpr int l = decltype(lc)::value + 1;
+    r = r + f[l];
+  });
+  rho = r;
+  static_for<3>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    if constexpr (a >= 3 - L::D) {
+      T acc = T(0);
+      static_for<L::Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int cl = L::c(a, l);
+        if constexpr (cl == 1) acc = acc + f[l];
+        if constexpr (cl == -1) acc = acc - f[l];
+      });
+      u[a] = acc / r;
+    } else {
+      u[a] = T(0);
+    }
+  });
+}
+
+template <class L, class T>
+__device__ __forceinline__ T usqr_of(const T (&u)[3]) {
+  T s = u[3 - L::D] * u[3 - L::D];
+  static_for<L::D - 1>([&](auto ac) {
+    constexpr int a = decltype(ac)::value + 1 + (3 - L::D);
+    s = s + u[a] * u[a];
+  });
+  return T(1.5) * s;
+}
+
+// feq_l for a compile-time direction l
+template <class L, class T, int l>
+__device__ __forceinline__ T feq_dir(T rho, const T (&u)[3], T usqr) {
+  T dot = T(0);
+  static_for<3>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    constexpr int cl = L::c(a, l);
+    if constexpr (a >= 3 - L::D) {
+      if constexpr (cl == 1) dot = dot + u[a];
+      if constexpr (cl == -1) dot = dot - u[a];
+    }
+  });
+  const T cu = T(3.0) * dot;
+  const T w = T(L::w(l));
+  return (rho * w) * ((T(1.0) + cu * (T(1.0) + T(0.5) * cu)) - usqr);
+}
+
+template <class L, class T>
+__device__ __forceinline__ void equilibrium(T rho, const T (&u)[3], T (&feq)[L::Q]) {
+  const T usqr = usqr_of<L, T>(u);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    feq[l] = feq_dir<L, T, l>(rho, u, usqr);
+  });
+}
+
+// ---- collisions (in place on f, given feq) ----------------------------------------
+template <class L, class T>
+__device__ __forceinline__ void bgk(T (&f)[L::Q], const T (&feq)[L::Q], T omega) {
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const T fneq = f[l] - feq[l];
+    f[l] = f[l] - omega * fneq;
+  });
+}
+
+template <class L, class T>
+__device__ __forceinline__ void second_moment(const T (&g)[L::Q], T (&pi)[6]) {
+  static_for<n_pi<L>()>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    T acc = T(0);
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int v = cc<L>(l, k);
+      if constexpr (v == 1) acc = acc + g[l];
+      if constexpr (v == -1) acc = acc - g[l];
+    });
+    pi[k] = acc;
+  });
+}
+
+// shear part delta_s of fneq; kbc.py:96-145 (D3Q27) and :147-174 then /4 (:61) (D2Q9)
+template <class L, class T>
+__device__ __forceinline__ void kbc_shear(const T (&pi)[6], T (&ds)[L::Q]) {
+  static_for<L::Q>([&](auto lc) { ds[decltype(lc)::value] = T(0); });
+  if constexpr (L::ID == XLBHIP_D3Q27) {
+    const T nxz = pi[0] - pi[5];
+    const T nyz = pi[3] - pi[5];
+    const T a = (T(2.0) * nxz - nyz) / T(6.0);
+    const T b = (-nxz + T(2.0) * nyz) / T(6.0);
+    const T c = (-nxz - nyz) / T(6.0);
+    ds[9] = a; ds[18] = a;
+    ds[3] = b; ds[6] = b;
+    ds[1] = c; ds[2] = c;
+    ds[12] = pi[1] / T(4.0); ds[24] = ds[12];
+    ds[21] = -pi[1] / T(4.0); ds[15] = ds[21];
+    ds[10] = pi[2] / T(4.0); ds[20] = ds[10];
+    ds[19] = -pi[2] / T(4.0); ds[11] = ds[19];
+    ds[8] = pi[4] / T(4.0); ds[4] = ds[8];
+    ds[7] = -pi[4] / T(4.0); ds[5] = ds[7];
+  } else if constexpr (L::ID == XLBHIP_D2Q9) {
+    const T n = pi[0] - pi[2];
+    ds[3] = n / T(4.0); ds[6] = ds[3];
+    ds[2] = -n / T(4.0); ds[1] = ds[2];
+    ds[8] = pi[1] / T(4.0); ds[7] = ds[8];
+    ds[4] = -pi[1] / T(4.0); ds[5] = ds[4];
+  }
+}
+
+template <class L, class T>
+__device__ __forceinline__ void kbc(T (&f)[L::Q], const T (&feq)[L::Q], T omega) {
+  T fneq[L::Q];
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    fneq[l] = f[l] - feq[l];
+  });
+  T pi[6];
+  second_moment<L, T>(fneq, pi);
+  T ds[L::Q];
+  kbc_shear<L, T>(pi, ds);
+  const T beta = T(0.5) * omega;
+  const T inv_beta = T(1.0) / beta;
+  T sp1 = T(0), sp2 = T(0);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const T dh = fneq[l] - ds[l];
+    const T t = dh / feq[l];
+    if constexpr (l == 0) {
+      sp1 = t * ds[l];
+      sp2 = t * dh;
+    } else {
+      sp1 = sp1 + t * ds[l];
+      sp2 = sp2 + t * dh;
+    }
+  });
+  const T gamma = inv_beta - ((T(2.0) - inv_beta) * sp1) / (T(1e-32) + sp2);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const T dh = fneq[l] - ds[l];
+    f[l] = f[l] - beta * (T(2.0) * ds[l] + gamma * dh);
+  });
+}
+
+template <class L, class T, int COLL>
+__device__ __forceinline__ void collide(T (&f)[L::Q], T omega) {
+  T rho, u[3];
+  moments<L, T>(f, rho, u);
+  T feq[L::Q];
+  equilibrium<L, T>(rho, u, feq);
+  if constexpr (COLL == XLBHIP_BGK)
+    bgk<L, T>(f, feq, omega);
+  else
+    kbc<L, T>(f, feq, omega);
+}
+
+}  // namespace xlb

@@ -1,0 +1,249 @@
+// Whole-field operator kernels (one thread per cell) and the boundary-masker kernels.
+// These mirror the reference's stand-alone operator launches; the
+// per-timestep hot path is the fused kernel in step_kernel.hpp.
+#pragma once
+#include "cell.hpp"
+
+namespace xlb {
+
+// Runtime-typed view of a field on the device.
+struct FieldView {
+  void* data;
+  size_t plane_stride;
+  int dtype;
+  int halo;
+};
+
+struct Dims {
+  int nx, ny, nz;
+};
+
+template <class T>
+__device__ __forceinline__ T load_rt(const FieldView& v, size_t i) {
+  switch (v.dtype) {
+    case XLBHIP_F64: return static_cast<T>(static_cast<const double*>(v.data)[i]);
+    case XLBHIP_F32: return static_cast<T>(static_cast<const float*>(v.data)[i]);
+    case XLBHIP_F16: return static_cast<T>(static_cast<const _Float16*>(v.data)[i]);
+    default: return static_cast<T>(static_cast<const uint8_t*>(v.data)[i]);
+  }
+}
+template <class T>
+__device__ __forceinline__ void store_rt(const FieldView& v, size_t i, T x) {
+  switch (v.dtype) {
+    case XLBHIP_F64: static_cast<double*>(v.data)[i] = static_cast<double>(x); break;
+    case XLBHIP_F32: static_cast<float*>(v.data)[i] = static_cast<float>(x); break;
+    case XLBHIP_F16: static_cast<_Float16*>(v.data)[i] = static_cast<_Float16>(x); break;
+    default: static_cast<uint8_t*>(v.data)[i] = static_cast<uint8_t>(x); break;
+  }
+}
+
+__device__ __forceinline__ bool cell_of_thread(const Dims& d, int& x, int& y, int& z) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)d.nx * d.ny * d.nz;
+  if (t >= n) return false;
+  z = (int)(t % d.nz);
+  const size_t r = t / d.nz;
+  y = (int)(r % d.ny);
+  x = (int)(r / d.ny);
+  return true;
+}
+__device__ __forceinline__ size_t cell_index(const FieldView& v, const Dims& d, int x, int y, int z) {
+  return ((size_t)(x + v.halo) * d.ny + y) * d.nz + z;
+}
+__device__ __forceinline__ int wrap(int i, int n) { return i < 0 ? i + n : (i >= n ? i - n : i); }
+
+// Stream()(f_0, f_1): stream.py:29-62 / :96-110 — periodic pull
+template <class L>
+__global__ void k_stream(FieldView src, FieldView dst, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t o = cell_index(dst, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const int xs = src.halo ? x - L::c(0, l) : wrap(x - L::c(0, l), d.nx);
+    const int ys = wrap(y - L::c(1, l), d.ny);
+    const int zs = wrap(z - L::c(2, l), d.nz);
+    const size_t i = (size_t)l * src.plane_stride + cell_index(src, d, xs, ys, zs);
+    // pure data movement: go through double, exact for every storage type
+    store_rt<double>(dst, (size_t)l * dst.plane_stride + o, load_rt<double>(src, i));
+  });
+}
+
+// QuadraticEquilibrium()(rho, u, f): quadratic_equilibrium.py:23-30
+template <class L, class T>
+__global__ void k_equilibrium(FieldView rho, FieldView u, FieldView f, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const T r = load_rt<T>(rho, cell_index(rho, d, x, y, z));
+  T uu[3] = {T(0), T(0), T(0)};
+  static_for<L::D>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    uu[a + 3 - L::D] = load_rt<T>(u, (size_t)a * u.plane_stride + cell_index(u, d, x, y, z));
+  });
+  T feq[L::Q];
+  equilibrium<L, T>(r, uu, feq);
+  const size_t o = cell_index(f, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    store_rt<T>(f, (size_t)l * f.plane_stride + o, feq[l]);
+  });
+}
+
+// Macroscopic()(f, rho, u): macroscopic.py:21-26
+template <class L, class T>
+__global__ void k_macroscopic(FieldView f, FieldView rho, FieldView u, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  T ff[L::Q];
+  const size_t i = cell_index(f, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    ff[l] = load_rt<T>(f, (size_t)l * f.plane_stride + i);
+  });
+  T r, uu[3];
+  moments<L, T>(ff, r, uu);
+  if (rho.data) store_rt<T>(rho, cell_index(rho, d, x, y, z), r);
+  if (u.data) {
+    static_for<L::D>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      store_rt<T>(u, (size_t)a * u.plane_stride + cell_index(u, d, x, y, z), uu[a + 3 - L::D]);
+    });
+  }
+}
+
+// SecondMoment()(f, pi): second_moment.py:55
+template <class L, class T>
+__global__ void k_second_moment(FieldView f, FieldView pi, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  T ff[L::Q];
+  const size_t i = cell_index(f, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    ff[l] = load_rt<T>(f, (size_t)l * f.plane_stride + i);
+  });
+  T p[6];
+  second_moment<L, T>(ff, p);
+  static_for<n_pi<L>()>([&](auto kc) {
+    constexpr int k = decltype(kc)::value;
+    store_rt<T>(pi, (size_t)k * pi.plane_stride + cell_index(pi, d, x, y, z), p[k]);
+  });
+}
+
+// BGK()/KBC()(f, feq, fout, omega): bgk.py:27-32, kbc.py:40-79
+template <class L, class T, int COLL>
+__global__ void k_collide(FieldView f, FieldView feq, FieldView fout, Dims d, T omega) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  T ff[L::Q], fe[L::Q];
+  const size_t i = cell_index(f, d, x, y, z), j = cell_index(feq, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    ff[l] = load_rt<T>(f, (size_t)l * f.plane_stride + i);
+    fe[l] = load_rt<T>(feq, (size_t)l * feq.plane_stride + j);
+  });
+  if constexpr (COLL == XLBHIP_BGK)
+    bgk<L, T>(ff, fe, omega);
+  else
+    kbc<L, T>(ff, fe, omega);
+  const size_t o = cell_index(fout, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    store_rt<T>(fout, (size_t)l * fout.plane_stride + o, ff[l]);
+  });
+}
+
+struct BcValues {
+  double v[27];
+};
+
+// bc(f_pre, f_post, bc_mask, missing_mask) -> f_post: boundary_condition.py:146-180 with the
+// JAX bodies of bc_equilibrium.py:75-80, bc_halfway_bounce_back.py:124-132,
+// bc_fullway_bounce_back.py:52-56, bc_do_nothing.py:50-54
+template <class L, class T>
+__global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, FieldView f_post, FieldView bc, FieldView miss,
+                           Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const uint8_t b = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+  if (b != id) return;
+  const size_t ip = cell_index(f_pre, d, x, y, z), io = cell_index(f_post, d, x, y, z);
+  unsigned m = 0;
+  if (kind == XLBHIP_BC_HALFWAY_BB) m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int o = opp<L>(l);
+    if (kind == XLBHIP_BC_EQUILIBRIUM) {
+      store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, static_cast<T>(vals.v[l]));
+    } else if (kind == XLBHIP_BC_HALFWAY_BB) {
+      if ((m >> l) & 1u)
+        store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io,
+                    load_rt<T>(f_pre, (size_t)o * f_pre.plane_stride + ip) + static_cast<T>(vals.v[l]));
+    } else if (kind == XLBHIP_BC_FULLWAY_BB) {
+      store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, load_rt<T>(f_pre, (size_t)o * f_pre.plane_stride + ip));
+    } else if (kind == XLBHIP_BC_DO_NOTHING) {
+      store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, load_rt<T>(f_pre, (size_t)l * f_pre.plane_stride + ip));
+    }
+  });
+}
+
+// ---- masker (indices_boundary_masker.py:73-143, JAX semantics) ---------------------------
+// scatter `value` at the listed GLOBAL indices that fall inside this rank's planes
+// [x_lo, x_hi) (storage plane = gx - x_lo)
+__global__ void k_scatter_u8(uint8_t* out, const int32_t* idx, int64_t n, uint8_t value, int x_lo, int x_hi, int gy,
+                             int gz) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = idx[i], y = idx[n + i], z = idx[2 * n + i];
+  if (x < x_lo || x >= x_hi || y < 0 || y >= gy || z < 0 || z >= gz) return;
+  out[((size_t)(x - x_lo) * gy + y) * gz + z] = value;
+}
+
+// missing[l, x] = (x - c_l outside the global domain) | solid[x - c_l] | old_missing[l, x - c_l]
+// solid has one ghost plane on each x side; old (bit-sets) uses the field's own halo.
+template <class L>
+__global__ void k_missing(uint32_t* out, const uint32_t* old, const uint8_t* solid, Dims d, int halo, int gnx, int x_offset) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  unsigned bits = 0;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const int xs = x - L::c(0, l), ys = y - L::c(1, l), zs = z - L::c(2, l);
+    const int gxs = xs + x_offset;
+    bool mis = gxs < 0 || gxs >= gnx || ys < 0 || ys >= d.ny || zs < 0 || zs >= d.nz;
+    if (!mis) {
+      mis = solid[((size_t)(xs + 1) * d.ny + ys) * d.nz + zs] != 0;
+      if (!mis && (halo > 0 || (xs >= 0 && xs < d.nx)))
+        mis = (old[((size_t)(xs + halo) * d.ny + ys) * d.nz + zs] >> l) & 1u;
+    }
+    bits |= (mis ? 1u : 0u) << l;
+  });
+  out[((size_t)(x + halo) * d.ny + y) * d.nz + z] = bits;
+}
+
+// pack / unpack the host (q, nx, ny, nz) u8 view of missing_mask <-> device bit-sets
+__global__ void k_pack_missing(const uint8_t* bytes, uint32_t* bits, int q, Dims d, int halo) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t n = (size_t)d.nx * d.ny * d.nz;
+  const size_t c = ((size_t)x * d.ny + y) * d.nz + z;
+  unsigned b = 0;
+  for (int l = 0; l < q; ++l) b |= (bytes[(size_t)l * n + c] ? 1u : 0u) << l;
+  bits[((size_t)(x + halo) * d.ny + y) * d.nz + z] = b;
+}
+__global__ void k_unpack_missing(const uint32_t* bits, uint8_t* bytes, int q, Dims d, int halo) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t n = (size_t)d.nx * d.ny * d.nz;
+  const size_t c = ((size_t)x * d.ny + y) * d.nz + z;
+  const unsigned b = bits[((size_t)(x + halo) * d.ny + y) * d.nz + z];
+  for (int l = 0; l < q; ++l) bytes[(size_t)l * n + c] = (b >> l) & 1u;
+}
+
+template <class E>
+__global__ void k_fill(E* p, size_t n, E v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace xlb

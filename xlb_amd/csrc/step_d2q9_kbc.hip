@@ -1,0 +1,7 @@
+// Instantiates the fused step kernel for D2Q9 / KBC (all precision policies).
+
+#include "step_launch.hpp"
+
+namespace xlb {
+int launch_step_d2q9_kbc(const StepLaunch& p) { return launch_step<D2Q9, XLBHIP_KBC>(p); }
+}  // namespace xlb

@@ -1,0 +1,111 @@
+// Type-erased launch descriptor + the per-(lattice, collision) dispatcher that each
+// step_*.hip translation unit instantiates.
+#pragma once
+#include "common.hpp"
+#include "step_kernel.hpp"
+
+namespace xlb {
+
+struct StepLaunch {
+  const void* src;
+  void* dst;
+  const uint8_t* bc;
+  const uint32_t* miss;
+  const uint8_t* tab_kind;
+  const void* tab_values;  // compute dtype [256][27]
+  size_t plane_stride;
+  int nx, ny, nz, halo;
+  int x_begin, x_count;
+  double omega;
+  int compute_dtype, store_dtype;
+  int vec;     // requested cells per thread (1, 2, 4); must divide nz
+  int has_bc;  // 0: bc_mask known to be all zero
+  int flags;   // bit 0: non-temporal stores
+  int block_threads;  // 0 = default (256)
+  hipStream_t stream;
+};
+
+// which (T, S, VEC) combinations exist: fp32 compute -> VEC in {1, 4}; fp64 compute -> {1, 2}
+inline int pick_vec(int compute_dtype, int nz, int requested) {
+  const int vmax = (compute_dtype == XLBHIP_F32) ? 4 : 2;
+  int v = requested > 0 ? requested : vmax;
+  if (v > vmax) v = vmax;
+  if (v == 3) v = 2;
+  if (compute_dtype == XLBHIP_F32 && v == 2) v = 1;  // no VEC=2 instantiation for fp32
+  if (nz % v != 0) v = 1;
+  return v;
+}
+
+template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
+int launch_typed(const StepLaunch& p) {
+  StepArgs<T, S> a;
+  a.src = static_cast<const S*>(p.src);
+  a.dst = static_cast<S*>(p.dst);
+  a.bc = p.bc;
+  a.miss = p.miss;
+  a.tab.kind = p.tab_kind;
+  a.tab.values = static_cast<const T*>(p.tab_values);
+  a.plane_stride = p.plane_stride;
+  a.nx = p.nx;
+  a.ny = p.ny;
+  a.nz = p.nz;
+  a.halo = p.halo;
+  a.x_begin = p.x_begin;
+  a.nzq = p.nz / VEC;
+  a.omega = static_cast<T>(p.omega);
+  const int threads = p.block_threads > 0 ? p.block_threads : 256;
+  int tz = a.nzq < threads ? a.nzq : threads;
+  int ty = threads / tz;
+  if (ty < 1) ty = 1;
+  if (ty > p.ny) ty = p.ny;
+  dim3 block(tz, ty, 1);
+  dim3 grid((a.nzq + tz - 1) / tz, (p.ny + ty - 1) / ty, p.x_count);
+  XLB_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "grid too large: ny/ty=%u x_count=%u", grid.y, grid.z);
+  hipLaunchKernelGGL((k_step<L, T, S, VEC, COLL, HASBC, FLAGS>), grid, block, 0, p.stream, a);
+  XLB_HIP(hipGetLastError());
+  return 0;
+}
+
+template <class L, class T, class S, int VEC, int COLL>
+int launch_vec(const StepLaunch& p) {
+  const bool nt = (p.flags & 1) != 0;
+#ifdef XLB_TUNE_VARIANTS
+  if (p.has_bc) return nt ? launch_typed<L, T, S, VEC, COLL, true, 1>(p) : launch_typed<L, T, S, VEC, COLL, true, 0>(p);
+  return nt ? launch_typed<L, T, S, VEC, COLL, false, 1>(p) : launch_typed<L, T, S, VEC, COLL, false, 0>(p);
+#else
+  (void)nt;
+  if (p.has_bc) return launch_typed<L, T, S, VEC, COLL, true, 1>(p);
+  return launch_typed<L, T, S, VEC, COLL, false, 1>(p);
+#endif
+}
+
+template <class L, class T, class S, int COLL>
+int launch_policy(const StepLaunch& p) {
+  const int v = pick_vec(p.compute_dtype, p.nz, p.vec);
+  if constexpr (sizeof(T) == 4) {
+    if (v == 4) return launch_vec<L, T, S, 4, COLL>(p);
+  } else {
+    if (v == 2) return launch_vec<L, T, S, 2, COLL>(p);
+  }
+  return launch_vec<L, T, S, 1, COLL>(p);
+}
+
+template <class L, int COLL>
+int launch_step(const StepLaunch& p) {
+  const int c = p.compute_dtype, s = p.store_dtype;
+  if (c == XLBHIP_F32 && s == XLBHIP_F32) return launch_policy<L, float, float, COLL>(p);
+  if (c == XLBHIP_F32 && s == XLBHIP_F16) return launch_policy<L, float, _Float16, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F64) return launch_policy<L, double, double, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F32) return launch_policy<L, double, float, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F16) return launch_policy<L, double, _Float16, COLL>(p);
+  XLB_FAIL("unsupported precision policy compute=%d store=%d", c, s);
+}
+
+// defined one per translation unit (step_<lattice>_<collision>.hip)
+int launch_step_d2q9_bgk(const StepLaunch& p);
+int launch_step_d2q9_kbc(const StepLaunch& p);
+int launch_step_d3q19_bgk(const StepLaunch& p);
+int launch_step_d3q27_bgk(const StepLaunch& p);
+int launch_step_d3q27_kbc(const StepLaunch& p);
+
+}  // namespace xlb

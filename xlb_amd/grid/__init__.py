@@ -1,0 +1,2 @@
+from .grid import grid_factory as grid_factory, Grid as Grid
+from .hip_grid import HipGrid as HipGrid

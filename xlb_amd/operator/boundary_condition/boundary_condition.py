@@ -1,0 +1,205 @@
+"""Boundary-condition base class, id registry and the four in-scope conditions.
+
+Reference: xlb/operator/boundary_condition/boundary_condition.py:26-136 (base, flags,
+``pad_indices``), boundary_condition_registry.py:6-30 (process-global id counter starting at 1,
+ids assigned in CONSTRUCTION order), bc_equilibrium.py, bc_halfway_bounce_back.py,
+bc_fullway_bounce_back.py, bc_do_nothing.py.
+
+Each BC is (a) a stand-alone operator ``bc(f_pre, f_post, bc_mask, missing_mask) -> f_post``
+and (b) a descriptor consumed by the fused stepper kernel (``_hip_descriptor``).
+"""
+
+from enum import Enum, auto
+
+import numpy as np
+
+from ... import _lib
+from ...compute_backend import ComputeBackend
+from ..equilibrium import Equilibrium, QuadraticEquilibrium
+from ..operator import Operator
+
+
+class ImplementationStep(Enum):
+    COLLISION = auto()
+    STREAMING = auto()
+
+
+class BoundaryConditionRegistry:
+    def __init__(self):
+        self.id_to_bc = {}
+        self.bc_to_id = {}
+        self.next_id = 1  # 0 = no boundary condition
+
+    def register_boundary_condition(self, boundary_condition):
+        _id = self.next_id
+        if _id > 253:
+            raise ValueError("more than 253 boundary conditions registered in this process (bc_mask is uint8)")
+        self.next_id += 1
+        self.id_to_bc[_id] = boundary_condition
+        self.bc_to_id[boundary_condition] = _id
+        return _id
+
+
+boundary_condition_registry = BoundaryConditionRegistry()
+
+
+class BoundaryCondition(Operator):
+    hip_kind = None
+
+    def __init__(
+        self,
+        implementation_step,
+        velocity_set=None,
+        precision_policy=None,
+        compute_backend=None,
+        indices=None,
+        mesh_vertices=None,
+        voxelization_method=None,
+    ):
+        self.id = boundary_condition_registry.register_boundary_condition(f"{self.__class__.__name__}_{id(self)}")
+        super().__init__(velocity_set, precision_policy, compute_backend)
+        if mesh_vertices is not None:
+            raise NotImplementedError("mesh-based boundary conditions are out of scope of the HIP backend (SURVEY.md section 8)")
+        self.indices = indices
+        self.mesh_vertices = None
+        self.voxelization_method = voxelization_method
+        self.implementation_step = implementation_step
+        self.needs_padding = False
+        self.needs_mesh_distance = False
+        self.needs_aux_init = False
+        self.is_initialized_with_aux_data = False
+        self.num_of_aux_data = 0
+        self.needs_aux_recovery = False
+
+    def pad_indices(self):
+        """Indices plus all their lattice neighbours (only when ``needs_padding``)."""
+        idx = np.array(self.indices)
+        if not self.needs_padding:
+            return idx
+        padded = idx[:, :, None] + self.velocity_set._c[:, None, :]
+        return np.unique(padded.reshape(self.velocity_set.d, -1), axis=1)
+
+    # descriptor for the C ABI: q constants in compute precision
+    def _hip_values(self):
+        return np.zeros(self.velocity_set.q)
+
+    def _hip_descriptor(self):
+        return _lib.make_bc_desc(self.id, self.hip_kind, self._hip_values())
+
+    def _apply(self, f_pre, f_post, bc_mask, missing_mask):
+        desc = self._hip_descriptor()
+        import ctypes
+
+        _lib.check(
+            _lib.load().xlbhip_apply_bc(
+                self._ctx.handle,
+                self.velocity_set.hip_id,
+                self._compute_code,
+                ctypes.byref(desc),
+                f_pre.handle,
+                f_post.handle,
+                bc_mask.handle,
+                missing_mask.handle if missing_mask is not None else None,
+            )
+        )
+        return f_post
+
+
+class EquilibriumBC(BoundaryCondition):
+    """f = feq(rho, u) at the tagged cells, after streaming."""
+
+    hip_kind = _lib.BC_EQUILIBRIUM
+
+    def __init__(self, rho, u, equilibrium_operator=None, velocity_set=None, precision_policy=None, compute_backend=None,
+                 indices=None, mesh_vertices=None, voxelization_method=None):
+        self.rho = rho
+        self.u = u
+        if equilibrium_operator is not None and not isinstance(equilibrium_operator, Equilibrium):
+            raise ValueError("Equilibrium operator must be a subclass of Equilibrium")
+        super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+        self.equilibrium_operator = equilibrium_operator or QuadraticEquilibrium(self.velocity_set, self.precision_policy, self.compute_backend)
+
+    def _hip_values(self):
+        return self.equilibrium_operator.host_values(self.rho, self.u).astype(np.float64)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class HalfwayBounceBackBC(BoundaryCondition):
+    """Missing populations are replaced by the opposite pre-streaming population of the same
+    cell (+ 6 w_l c_l.u_wall for a moving wall), after streaming."""
+
+    hip_kind = _lib.BC_HALFWAY_BB
+
+    def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None, indices=None, mesh_vertices=None,
+                 voxelization_method=None, profile=None, prescribed_value=None):
+        super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+        self.needs_padding = True
+        if profile is not None:
+            if prescribed_value is not None:
+                raise ValueError("Cannot specify both profile and prescribed_value")
+            raise NotImplementedError("callable wall-velocity profiles are out of scope of the HIP backend; use prescribed_value")
+        self.needs_moving_wall_treatment = prescribed_value is not None
+        if prescribed_value is None:
+            print(f"WARNING! Assuming no-slip condition for BC type = {self.__class__.__name__}!")
+            prescribed_value = [0] * self.velocity_set.d
+        if not isinstance(prescribed_value, (tuple, list, np.ndarray)):
+            raise ValueError("Velocity prescribed_value must be a tuple, list, or array")
+        self.prescribed_value = np.asarray(prescribed_value, dtype=np.float64)
+        if self.prescribed_value.shape != (self.velocity_set.d,):
+            raise ValueError(f"prescribed_value must have {self.velocity_set.d} components")
+
+    def _hip_values(self):
+        vs = self.velocity_set
+        T, S = self.compute_dtype, self.store_dtype
+        out = np.zeros(vs.q, dtype=T)
+        if not self.needs_moving_wall_treatment:
+            return out.astype(np.float64)
+        # bc_halfway_bounce_back.py:97-102,124-128: u_wall in STORE precision, 6 * (w * (c . u_wall))
+        uw = self.prescribed_value.astype(S)
+        w = vs._w.astype(T)
+        for l in range(vs.q):
+            dot = S(0)
+            for d in range(vs.d):
+                dot = S(dot + S(int(vs._c[d, l])) * uw[d])
+            out[l] = T(T(6.0) * T(w[l] * T(dot)))
+        return out.astype(np.float64)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class FullwayBounceBackBC(BoundaryCondition):
+    """Every population of a tagged cell is replaced by the opposite post-streaming population,
+    after collision."""
+
+    hip_kind = _lib.BC_FULLWAY_BB
+
+    def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None, indices=None, mesh_vertices=None,
+                 voxelization_method=None):
+        super().__init__(ImplementationStep.COLLISION, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class DoNothingBC(BoundaryCondition):
+    """Tagged cells keep their pre-streaming populations."""
+
+    hip_kind = _lib.BC_DO_NOTHING
+
+    def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None, indices=None, mesh_vertices=None,
+                 voxelization_method=None):
+        super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)

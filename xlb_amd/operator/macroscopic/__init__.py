@@ -1,0 +1,1 @@
+from .macroscopic import Macroscopic as Macroscopic, ZeroMoment as ZeroMoment, FirstMoment as FirstMoment, SecondMoment as SecondMoment

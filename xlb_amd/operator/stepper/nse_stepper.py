@@ -1,0 +1,100 @@
+"""Incompressible Navier-Stokes stepper: one fused HIP kernel per time step.
+
+Reference: xlb/operator/stepper/nse_stepper.py — constructor :65-97, ``prepare_fields``
+:99-148, boundary processing :150-205, the step itself :237-282 (JAX order, the parity
+target) / :427-476 (fused Warp kernel, the structural model).
+
+    stepper = IncompressibleNavierStokesStepper(grid, boundary_conditions, collision_type="BGK")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    for i in range(n):
+        f_0, f_1 = stepper(f_0, f_1, bc_mask, missing_mask, omega, i)
+        f_0, f_1 = f_1, f_0
+
+``stepper.run(f_0, f_1, bc_mask, missing_mask, omega, n_steps)`` runs the same loop natively
+(no per-step Python dispatch, which costs tens of microseconds per call in the reference's
+``Operator.__call__``).
+"""
+
+from ... import _lib
+from ...compute_backend import ComputeBackend
+from ...helper.check_boundary_overlaps import check_bc_overlaps
+from ...helper.initializers import initialize_eq
+from ...helper.nse_fields import create_nse_fields
+from ..boundary_condition import ImplementationStep
+from ..boundary_masker import IndicesBoundaryMasker
+from ..collision import BGK, KBC
+from ..equilibrium import QuadraticEquilibrium
+from ..macroscopic import Macroscopic
+from ..operator import Operator
+from ..stream import Stream
+from .stepper import Stepper
+
+
+class IncompressibleNavierStokesStepper(Stepper):
+    def __init__(self, grid, boundary_conditions=[], collision_type="BGK", streaming_scheme="pull",
+                 forcing_scheme="exact_difference", force_vector=None, backend_config={}):
+        self.backend_config = dict(backend_config or {})
+        self.collision_type = collision_type
+        self.streaming_scheme = streaming_scheme
+        if streaming_scheme != "pull":
+            raise AssertionError(f"Unknown or unimplemented streaming scheme for backend: {ComputeBackend.HIP}")
+        if force_vector is not None:
+            raise NotImplementedError("ForcedCollision is out of scope of the HIP backend (SURVEY.md section 8f)")
+        self._native = None
+        super().__init__(grid, boundary_conditions)
+        vs, pp, be = self.velocity_set, self.precision_policy, self.compute_backend
+        if collision_type == "BGK":
+            self.collision = BGK(vs, pp, be)
+        elif collision_type == "KBC":
+            self.collision = KBC(vs, pp, be)
+        else:
+            raise NotImplementedError(f"collision_type {collision_type!r} is out of scope of the HIP backend (BGK, KBC)")
+        self.stream = Stream(vs, pp, be)
+        self.equilibrium = QuadraticEquilibrium(vs, pp, be)
+        self.macroscopic = Macroscopic(vs, pp, be)
+
+    # -- native stepper object, created lazily (BC ids and constants are final by then)
+    def _native_stepper(self):
+        if self._native is None:
+            descs = [bc._hip_descriptor() for bc in self.boundary_conditions]
+            self._native = _lib.Stepper(self._ctx, self.velocity_set.hip_id, self.collision.hip_collision_id, self._compute_code,
+                                        self._store_code, descs)
+        return self._native
+
+    def prepare_fields(self, initializer=None):
+        _, f_0, f_1, missing_mask, bc_mask = create_nse_fields(
+            grid=self.grid, velocity_set=self.velocity_set, compute_backend=self.compute_backend, precision_policy=self.precision_policy
+        )
+        f_1, bc_mask, missing_mask = self._process_boundary_conditions(self.boundary_conditions, f_1, bc_mask, missing_mask)
+        if initializer is not None:
+            f_0 = initializer(bc_mask, f_0)
+        else:
+            f_0 = initialize_eq(f_0, self.grid, self.velocity_set, self.precision_policy, self.compute_backend)
+        return f_0, f_1, bc_mask, missing_mask
+
+    def _process_boundary_conditions(self, boundary_conditions, f_1, bc_mask, missing_mask):
+        check_bc_overlaps(boundary_conditions, self.velocity_set.d, self.compute_backend)
+        masker = IndicesBoundaryMasker(self.velocity_set, self.precision_policy, self.compute_backend, grid=self.grid)
+        with_indices = [bc for bc in boundary_conditions if getattr(bc, "indices", None) is not None]
+        if with_indices:
+            bc_mask, missing_mask = masker(with_indices, bc_mask, missing_mask)
+        return f_1, bc_mask, missing_mask
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_0, f_1, bc_mask, missing_mask, omega, timestep):
+        self._native_stepper().step(f_0, f_1, bc_mask, missing_mask, omega, timestep)
+        return f_0, f_1
+
+    def run(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
+        """``n_steps`` x (step, swap) in native code; returns (f_current, f_other)."""
+        self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
+        return (f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)
+
+    def run_timed(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
+        """As :meth:`run`; also returns the device time in ms measured with HIP events."""
+        ms = self._native_stepper().run_timed(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
+        return ((f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)), ms
+
+    @property
+    def has_post_streaming_bc(self):
+        return any(bc.implementation_step == ImplementationStep.STREAMING for bc in self.boundary_conditions)
