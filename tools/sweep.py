@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Interleaved A/B sweep of backend options on one workload, in ONE process (methodology rule:
+perf deltas come from interleaved rounds in one process).  Prints median / min ms per step.
+
+    python tools/sweep.py --workload periodic --size 512 --rounds 3 --steps 20 \
+        --variant vec=4 --variant vec=1 --variant "vec=4,nt_store=0"
+"""
+
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="periodic")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--lattice", default="D3Q19")
+    ap.add_argument("--collision", default="BGK")
+    ap.add_argument("--policy", default="FP32FP32")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--variant", action="append", default=[])
+    ap.add_argument("--realloc", action="store_true", help="variants change the field layout (plane_pad_bytes): rebuild fields per variant")
+    args = ap.parse_args()
+
+    import xlb_amd
+    from bench import cavity_bcs
+    from xlb_amd import ComputeBackend, PrecisionPolicy
+    from xlb_amd.default_config import get_context
+    from xlb_amd.grid import grid_factory
+    from xlb_amd.operator.boundary_condition import EquilibriumBC, FullwayBounceBackBC, HalfwayBounceBackBC
+    from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
+
+    pp = PrecisionPolicy[args.policy]
+    vs = getattr(xlb_amd.velocity_set, args.lattice)(precision_policy=pp, compute_backend=ComputeBackend.HIP)
+    xlb_amd.init(velocity_set=vs, default_backend=ComputeBackend.HIP, default_precision_policy=pp)
+    ctx = get_context()
+    defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap")}
+    n = args.size
+
+    def setup():
+        grid = grid_factory((n, n, n))
+        if args.workload == "periodic":
+            bcs = []
+        else:
+            bcs = cavity_bcs(grid, HalfwayBounceBackBC if args.workload == "cavity_halfway" else FullwayBounceBackBC, EquilibriumBC)
+        st = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type=args.collision)
+        return st, st.prepare_fields()
+
+    def apply(variant):
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
+        for kv in filter(None, variant.split(",")):
+            k, v = kv.split("=")
+            ctx.set_option(k, int(v))
+
+    variants = args.variant or [""]
+    times = {v: [] for v in variants}
+    shared = None if args.realloc else setup()
+    for r in range(args.rounds):
+        for v in variants:
+            apply(v)
+            st, (f0, f1, bm, mm) = shared if shared else setup()
+            st.run(f0, f1, bm, mm, 1.0, 4)
+            ctx.sync()
+            _, ms = st.run_timed(f0, f1, bm, mm, 1.0, args.steps)
+            times[v].append(ms / args.steps)
+            if not shared:
+                for fld in (f0, f1, bm, mm):
+                    fld.free()
+    cells = float(n) ** 3
+    b_alg = 2 * vs.q * pp.store_precision.np_dtype(0).itemsize
+    print(f"# {args.lattice} {args.collision} {args.policy} {args.workload} {n}^3, {args.steps} steps x {args.rounds} rounds")
+    print(f"{'variant':44s} {'med ms':>8s} {'min ms':>8s} {'MLUPS(med)':>11s} {'GB/s':>8s} {'frac':>6s}")
+    for v in variants:
+        t = np.array(times[v])
+        med, mn = float(np.median(t)), float(t.min())
+        gbs = b_alg * cells / (med * 1e-3) / 1e9
+        print(f"{(v or 'default'):44s} {med:8.4f} {mn:8.4f} {cells / med / 1e3:11.1f} {gbs:8.1f} {gbs / 8000:6.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -109,10 +109,11 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   XLB_HIP(hipGetDeviceProperties(&p, device));
   c->compute_units = p.multiProcessorCount;
   // defaults of the tuning knobs
-  c->opts["vec"] = 0;              // 0 = widest available
+  c->opts["vec"] = 0;              // cells per thread: 0 = auto (1), or 1 / 2 / 4
   c->opts["nt_store"] = 1;         // non-temporal stores in the fused kernel
   c->opts["plane_pad_bytes"] = 4352;  // de-alias the q population planes
   c->opts["block_threads"] = 256;
+  c->opts["block_tz"] = 0;         // threads along z per block (0 = a whole row when it fits)
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
   *out = c;
   return 0;
@@ -512,6 +513,8 @@ struct xlbhip_stepper {
   int n_bc = 0;
   bool needs_missing = false;
   uint8_t* tab_kind = nullptr;  // device [256]
+  unsigned long long ids_packed = 0;
+  unsigned kinds_packed = 0;
   void* tab_values = nullptr;   // device [256][27] compute dtype
 };
 
@@ -554,6 +557,9 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.bc = (s->n_bc > 0 && bcm) ? static_cast<const uint8_t*>(bcm->data) : nullptr;
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
   p.tab_kind = s->tab_kind;
+  p.ids_packed = s->ids_packed;
+  p.kinds_packed = s->kinds_packed;
+  p.n_bc = s->n_bc;
   p.tab_values = s->tab_values;
   p.plane_stride = src->plane_stride;
   p.nx = src->nx;
@@ -567,6 +573,7 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.has_bc = p.bc != nullptr;
   p.flags = opt(c, "nt_store", 1) ? 1 : 0;
   p.block_threads = (int)opt(c, "block_threads", 256);
+  p.block_tz = (int)opt(c, "block_tz", 0);
   p.stream = c->stream;
   if (src->halo == 0) {
     p.x_begin = 0;
@@ -623,6 +630,12 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
     for (int l = 0; l < q; ++l) vals[b.id * 27 + l] = b.values[l];
     if (b.kind == XLBHIP_BC_HALFWAY_BB) needs_missing = true;
   }
+  unsigned long long ids_packed = 0;
+  unsigned kinds_packed = 0;
+  for (int i = 0; i < n_bc && i < 8; ++i) {
+    ids_packed |= (unsigned long long)(bcs[i].id & 0xff) << (8 * i);
+    kinds_packed |= (unsigned)(bcs[i].kind & 0xf) << (4 * i);
+  }
   XLB_HIP(hipSetDevice(c->device));
   xlbhip_stepper* s = new xlbhip_stepper();
   s->ctx = c;
@@ -632,6 +645,8 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   s->sdt = sdt;
   s->n_bc = n_bc;
   s->needs_missing = needs_missing;
+  s->ids_packed = ids_packed;
+  s->kinds_packed = kinds_packed;
   XLB_HIP(hipMalloc(&s->tab_kind, 256));
   XLB_HIP(hipMemcpy(s->tab_kind, kind.data(), 256, hipMemcpyHostToDevice));
   if (cdt == XLBHIP_F32) {

@@ -5,34 +5,39 @@
 // with the step ORDER and semantics of the JAX branch (:237-282), which is the parity
 // target.  Design:
 //   * SoA populations (q, x, y, z), z fastest; a thread owns VEC consecutive z cells
-//     and keeps their q populations in registers (VEC*q VGPRs), so moments/feq/collide
-//     need no cross-lane traffic at all.
-//   * per direction ONE vector load per thread: 16-B aligned for c_z == 0, dword-aligned
-//     (shifted by one element) for c_z = +-1; the single wrapped element at a row end is
-//     patched by an exec-masked scalar load.  x is block-uniform (blockIdx.z), so the
-//     plane/x part of every address is scalar (SGPR) arithmetic.
-//   * boundary cells are handled in-register on a slow path taken only by threads whose
-//     bc_mask word is non-zero; missing bits (one u32 per cell) and own-cell pre-stream
-//     populations are fetched only there.
-//   * stores are 16-B aligned vector stores, optionally non-temporal.
+//     and keeps their q populations in registers, so moments/feq/collide need no
+//     cross-lane traffic at all.
+//   * every global access is `uniform base (SGPR pair) + 32-bit byte offset (VGPR)`: x is
+//     block-uniform (blockIdx.z), so the population-plane / x-plane part of each address is
+//     scalar arithmetic and the q loads share nine per-thread (y, z) neighbour offsets.
+//   * per direction ONE load per thread: aligned for c_z == 0, shifted by one element for
+//     c_z = +-1 (dword-aligned vector load when VEC > 1; the single wrapped element at a row
+//     end is patched by an exec-masked scalar load).
+//   * boundary cells are handled in-register on a slow path taken only by lanes whose
+//     bc_mask byte is non-zero; the id -> kind lookup is a scalar compare chain on kernel
+//     arguments (no dependent table load), and missing bits (one u32 per cell) and own-cell
+//     pre-stream populations are fetched only there.
+//   * stores are aligned (vector) stores, optionally non-temporal.
 #pragma once
 #include "cell.hpp"
 
 namespace xlb {
 
-template <class T>
-struct BcTableDev {
-  const uint8_t* kind;  // [256] XLBHIP_BC_* or 0
-  const T* values;      // [256][27]
-};
+// kinds as the kernel sees them
+enum { K_NONE = 0, K_EQ = XLBHIP_BC_EQUILIBRIUM, K_HW = XLBHIP_BC_HALFWAY_BB, K_FW = XLBHIP_BC_FULLWAY_BB, K_DN = XLBHIP_BC_DO_NOTHING };
+constexpr int MAX_FAST_BCS = 8;
 
 template <class T, class S>
 struct StepArgs {
   const S* src;
   S* dst;
-  const uint8_t* bc;     // (nx+2h, ny, nz) or nullptr
-  const uint32_t* miss;  // (nx+2h, ny, nz) bit-sets or nullptr
-  BcTableDev<T> tab;
+  const uint8_t* bc;      // (nx+2h, ny, nz) or nullptr
+  const uint32_t* miss;   // (nx+2h, ny, nz) bit-sets or nullptr
+  const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
+  const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS
+  unsigned long long ids_packed;  // up to 8 bc ids, one per byte
+  unsigned kinds_packed;          // their kinds, one per nibble
+  int n_bc;
   size_t plane_stride;  // elements
   int nx, ny, nz;       // interior extent of this rank
   int halo;             // ghost planes per side (0: periodic wrap in x done here)
@@ -46,50 +51,81 @@ struct VecOf {
   typedef S aligned __attribute__((ext_vector_type(N), aligned(sizeof(S) * N)));
   typedef S shifted __attribute__((ext_vector_type(N), aligned(sizeof(S))));
 };
-template <class S>
-struct VecOf<S, 1> {
-  typedef S aligned;
-  typedef S shifted;
-};
 
+// p = uniform base, boff = per-thread byte offset (32 bit) -> global_load ... v_off, s[base]
+template <class S>
+__device__ __forceinline__ S ld(const S* base, unsigned boff) {
+  return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + boff);
+}
 template <class S, int VEC>
-__device__ __forceinline__ void load_aligned(const S* p, S (&out)[VEC]) {
+__device__ __forceinline__ void ld_aligned(const S* base, unsigned boff, S (&out)[VEC]) {
   if constexpr (VEC == 1) {
-    out[0] = *p;
+    out[0] = ld(base, boff);
   } else {
-    typename VecOf<S, VEC>::aligned v = *reinterpret_cast<const typename VecOf<S, VEC>::aligned*>(p);
+    typedef typename VecOf<S, VEC>::aligned V;
+    const V v = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + boff);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) out[k] = v[k];
   }
 }
 template <class S, int VEC>
-__device__ __forceinline__ void load_shifted(const S* p, S (&out)[VEC]) {
-  typename VecOf<S, VEC>::shifted v = *reinterpret_cast<const typename VecOf<S, VEC>::shifted*>(p);
+__device__ __forceinline__ void ld_shifted(const S* base, unsigned boff, S (&out)[VEC]) {
+  typedef typename VecOf<S, VEC>::shifted V;
+  const V v = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + boff);
 #pragma unroll
   for (int k = 0; k < VEC; ++k) out[k] = v[k];
 }
 template <class S, int VEC, bool NT>
-__device__ __forceinline__ void store_aligned(S* p, const S (&in)[VEC]) {
+__device__ __forceinline__ void st_aligned(S* base, unsigned boff, const S (&in)[VEC]) {
+  char* p = reinterpret_cast<char*>(base) + boff;
   if constexpr (VEC == 1) {
     if constexpr (NT)
-      __builtin_nontemporal_store(in[0], p);
+      __builtin_nontemporal_store(in[0], reinterpret_cast<S*>(p));
     else
-      *p = in[0];
+      *reinterpret_cast<S*>(p) = in[0];
   } else {
-    typename VecOf<S, VEC>::aligned v;
+    typedef typename VecOf<S, VEC>::aligned V;
+    V v;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] = in[k];
     if constexpr (NT)
-      __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<S, VEC>::aligned*>(p));
+      __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
     else
-      *reinterpret_cast<typename VecOf<S, VEC>::aligned*>(p) = v;
+      *reinterpret_cast<V*>(p) = v;
   }
+}
+
+// Identity the optimiser cannot see through.  The BC branches below issue loads that are
+// textually identical across branches (own-cell populations, per-BC constants); LLVM would hoist
+// them above the branch and keep ~40 extra VGPRs live in the fluid fast path.
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <class P>
+__device__ __forceinline__ const P* opaque(const P* p) {
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
+template <class T, class S>
+__device__ __forceinline__ unsigned kind_of(const StepArgs<T, S>& a, unsigned id) {
+  if (a.n_bc > MAX_FAST_BCS) return a.bc_kind[id];
+  unsigned kind = K_NONE;
+#pragma unroll
+  for (int s = 0; s < MAX_FAST_BCS; ++s) {
+    const unsigned sid = (unsigned)(a.ids_packed >> (8 * s)) & 0xffu;  // scalar
+    const unsigned sk = (a.kinds_packed >> (4 * s)) & 0xfu;            // scalar
+    kind = (id == sid) ? sk : kind;
+  }
+  return kind;
 }
 
 // FLAGS bit 0: non-temporal stores
 template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
 __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
   constexpr int Q = L::Q;
+  constexpr unsigned ES = sizeof(S);
   const int zq = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (zq >= a.nzq || y >= a.ny) return;
@@ -97,8 +133,8 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
   const int z0 = zq * VEC;
   const int ny = a.ny, nz = a.nz;
 
-  // storage x-plane indices of the three x neighbours (uniform)
-  int Xs[3];  // index by cx + 1 -> source plane for c_x = -1, 0, +1 is x - c_x
+  // storage x-plane of the source for c_x = -1, 0, +1 (index c_x + 1); uniform
+  int Xs[3];
   if (a.halo) {
     Xs[0] = x + a.halo + 1;
     Xs[1] = x + a.halo;
@@ -109,14 +145,15 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
     Xs[2] = (x == 0) ? a.nx - 1 : x - 1;
   }
   const size_t plane_cells = (size_t)ny * nz;
-  // row offsets inside an x-plane for the three y neighbours (per thread, 32 bit)
-  unsigned Yo[3];
-  Yo[0] = (unsigned)((y + 1 == ny) ? 0 : y + 1) * (unsigned)nz;
-  Yo[1] = (unsigned)y * (unsigned)nz;
-  Yo[2] = (unsigned)((y == 0) ? ny - 1 : y - 1) * (unsigned)nz;
+  // byte offsets inside an x-plane of the three y-neighbour rows (index c_y + 1)
+  unsigned Yb[3];
+  Yb[0] = (unsigned)((y + 1 == ny) ? 0 : y + 1) * (unsigned)nz * ES;
+  Yb[1] = (unsigned)y * (unsigned)nz * ES;
+  Yb[2] = (unsigned)((y == 0) ? ny - 1 : y - 1) * (unsigned)nz * ES;
 
   const bool at_z_lo = (z0 == 0);
   const bool at_z_hi = (z0 + VEC == nz);
+  const unsigned zb = (unsigned)z0 * ES;
 
   T f[VEC][Q];
 
@@ -125,31 +162,29 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
     constexpr int l = decltype(lc)::value;
     constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
     const S* row = a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells;  // uniform
-    const unsigned yo = Yo[cy + 1];
+    const unsigned yb = Yb[cy + 1];
     S v[VEC];
     if constexpr (cz == 0) {
-      load_aligned<S, VEC>(row + (yo + (unsigned)z0), v);
+      ld_aligned<S, VEC>(row, yb + zb, v);
     } else if constexpr (VEC == 1) {
       int zs = z0 - cz;
       zs = zs < 0 ? nz - 1 : (zs == nz ? 0 : zs);
-      v[0] = row[yo + (unsigned)zs];
+      v[0] = ld(row, yb + (unsigned)zs * ES);
     } else if constexpr (cz == 1) {
       // need z0-1 .. z0+VEC-2 ; at the row start z0-1 wraps to nz-1
-      const unsigned off = yo + (unsigned)z0 - (at_z_lo ? 0u : 1u);
       S t[VEC];
-      load_shifted<S, VEC>(row + off, t);
+      ld_shifted<S, VEC>(row, yb + zb - (at_z_lo ? 0u : ES), t);
       S wrapv = t[0];
-      if (at_z_lo) wrapv = row[yo + (unsigned)(nz - 1)];
+      if (at_z_lo) wrapv = ld(row, yb + (unsigned)(nz - 1) * ES);
       v[0] = at_z_lo ? wrapv : t[0];
 #pragma unroll
       for (int k = 1; k < VEC; ++k) v[k] = at_z_lo ? t[k - 1] : t[k];
     } else {
       // cz == -1: need z0+1 .. z0+VEC ; at the row end z0+VEC wraps to 0
-      const unsigned off = yo + (unsigned)z0 + (at_z_hi ? 0u : 1u);
       S t[VEC];
-      load_shifted<S, VEC>(row + off, t);
+      ld_shifted<S, VEC>(row, yb + zb + (at_z_hi ? 0u : ES), t);
       S wrapv = t[VEC - 1];
-      if (at_z_hi) wrapv = row[yo];
+      if (at_z_hi) wrapv = ld(row, yb);
 #pragma unroll
       for (int k = 0; k < VEC - 1; ++k) v[k] = at_z_hi ? t[k + 1] : t[k];
       v[VEC - 1] = at_z_hi ? wrapv : t[VEC - 1];
@@ -159,30 +194,26 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
   });
 
   // ---- boundary ids of my VEC cells ----
-  const size_t cell0 = (size_t)Xs[1] * plane_cells + Yo[1] + (unsigned)z0;
+  const unsigned cell_in_plane = (unsigned)y * (unsigned)nz + (unsigned)z0;  // elements, < 2^30
   unsigned ids[VEC];
   bool any_bc = false;
   if constexpr (HASBC) {
+    const uint8_t* bcp = a.bc + (size_t)Xs[1] * plane_cells;  // uniform
     if constexpr (VEC == 4) {
-      const unsigned wrd = *reinterpret_cast<const unsigned*>(a.bc + cell0);
+      const unsigned wrd = ld(reinterpret_cast<const unsigned*>(bcp), cell_in_plane);
       any_bc = wrd != 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) ids[k] = (wrd >> (8 * k)) & 0xffu;
     } else if constexpr (VEC == 2) {
-      const unsigned wrd = *reinterpret_cast<const unsigned short*>(a.bc + cell0);
+      const unsigned wrd = ld(reinterpret_cast<const unsigned short*>(bcp), cell_in_plane);
       any_bc = wrd != 0u;
       ids[0] = wrd & 0xffu;
       ids[1] = (wrd >> 8) & 0xffu;
     } else {
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) {
-        ids[k] = a.bc[cell0 + k];
-        any_bc |= ids[k] != 0u;
-      }
+      ids[0] = ld(bcp, cell_in_plane);
+      any_bc = ids[0] != 0u;
     }
   }
-
-  const S* own = a.src + cell0;  // own-cell pre-stream populations: own[l * plane_stride + k]
 
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
@@ -190,28 +221,45 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
     if constexpr (HASBC) {
       if (any_bc && ids[k] != 0u) {
         const unsigned id = ids[k];
-        const unsigned kind = a.tab.kind[id];
-        const T* val = a.tab.values + id * 27u;
-        if (kind == XLBHIP_BC_EQUILIBRIUM) {
+        const unsigned kind = kind_of(a, id);
+        const unsigned cb = (cell_in_plane + (unsigned)k) * ES;  // own cell, byte offset in the x-plane
+        if (kind == K_EQ) {
           // bc_equilibrium.py:75-80: f = feq(rho0, u0)
+          const T* val = opaque(a.bc_values + id * 27u);
           static_for<Q>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
             f[k][l] = val[l];
           });
-        } else if (kind == XLBHIP_BC_HALFWAY_BB) {
-          // bc_halfway_bounce_back.py:124-132: missing & boundary -> f_pre[opp] + moving wall term
-          const unsigned m = a.miss[cell0 + k];
-          static_for<Q>([&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            if ((m >> l) & 1u) f[k][l] = to_compute<T, S>(own[(size_t)opp<L>(l) * a.plane_stride + k]) + val[l];
+        } else if (kind == K_HW) {
+          // bc_halfway_bounce_back.py:124-132: missing & boundary -> f_pre[opp] + moving-wall term
+          // (the term is 0.0 for a no-slip wall; the reference adds it in that case too).
+          // Rare path: processed in groups of 4 directions so that the temporaries do not
+          // raise the register allocation of the whole kernel.
+          const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, (cell_in_plane + (unsigned)k) * 4u);
+          const T* val = opaque(a.bc_values + id * 27u);
+          const unsigned cbh = opaque(cb);
+          static_for<(Q + 3) / 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<4>([&](auto jc) {
+              constexpr int l = g * 4 + decltype(jc)::value;
+              if constexpr (l < Q) {
+                const S* own = a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)Xs[1] * plane_cells;  // uniform
+                const T pre = to_compute<T, S>(ld(own, cbh)) + val[l];
+                if ((m >> l) & 1u) f[k][l] = pre;
+              }
+            });
           });
-        } else if (kind == XLBHIP_BC_DO_NOTHING) {
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (kind == K_DN) {
           // bc_do_nothing.py:50-54
+          const unsigned cbd = opaque(cb);
           static_for<Q>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
-            f[k][l] = to_compute<T, S>(own[(size_t)l * a.plane_stride + k]);
+            const S* own = a.src + (size_t)l * a.plane_stride + (size_t)Xs[1] * plane_cells;
+            f[k][l] = to_compute<T, S>(ld(own, cbd));
           });
-        } else if (kind == XLBHIP_BC_FULLWAY_BB) {
+        } else if (kind == K_FW) {
           fullway = true;
         }
       }
@@ -233,13 +281,13 @@ __global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
   }
 
   // ---- store (cast to store precision, nse_stepper.py:280) ----
-  S* drow = a.dst + cell0;
   static_for<Q>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
+    S* drow = a.dst + (size_t)l * a.plane_stride + (size_t)Xs[1] * plane_cells;  // uniform
     S v[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) v[k] = to_store<S, T>(f[k][l]);
-    store_aligned<S, VEC, (FLAGS & 1) != 0>(drow + (size_t)l * a.plane_stride, v);
+    st_aligned<S, VEC, (FLAGS & 1) != 0>(drow, Yb[1] + zb, v);
   });
 }
 

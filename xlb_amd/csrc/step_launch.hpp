@@ -13,6 +13,9 @@ struct StepLaunch {
   const uint32_t* miss;
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
+  unsigned long long ids_packed;
+  unsigned kinds_packed;
+  int n_bc;
   size_t plane_stride;
   int nx, ny, nz, halo;
   int x_begin, x_count;
@@ -22,16 +25,19 @@ struct StepLaunch {
   int has_bc;  // 0: bc_mask known to be all zero
   int flags;   // bit 0: non-temporal stores
   int block_threads;  // 0 = default (256)
+  int block_tz;       // threads along z per block, 0 = as many as fit
   hipStream_t stream;
 };
 
-// which (T, S, VEC) combinations exist: fp32 compute -> VEC in {1, 4}; fp64 compute -> {1, 2}
+// which (T, S, VEC) combinations exist: fp32 compute -> VEC in {1, 2, 4}; fp64 compute -> {1, 2}
 inline int pick_vec(int compute_dtype, int nz, int requested) {
+  // Measured on MI355X (profiles/r01_sweeps.md): one cell per thread wins for D3Q19 fp32 at 512^3
+  // (44-60 VGPRs -> 8 waves/SIMD; 75.9 % of the HBM peak vs 74.5 % for VEC=2 and 72.9 % for VEC=4),
+  // so "auto" (0) means 1.  Wider variants stay selectable through the "vec" option.
   const int vmax = (compute_dtype == XLBHIP_F32) ? 4 : 2;
-  int v = requested > 0 ? requested : vmax;
+  int v = requested > 0 ? requested : 1;
   if (v > vmax) v = vmax;
   if (v == 3) v = 2;
-  if (compute_dtype == XLBHIP_F32 && v == 2) v = 1;  // no VEC=2 instantiation for fp32
   if (nz % v != 0) v = 1;
   return v;
 }
@@ -43,8 +49,11 @@ int launch_typed(const StepLaunch& p) {
   a.dst = static_cast<S*>(p.dst);
   a.bc = p.bc;
   a.miss = p.miss;
-  a.tab.kind = p.tab_kind;
-  a.tab.values = static_cast<const T*>(p.tab_values);
+  a.bc_kind = p.tab_kind;
+  a.bc_values = static_cast<const T*>(p.tab_values);
+  a.ids_packed = p.ids_packed;
+  a.kinds_packed = p.kinds_packed;
+  a.n_bc = p.n_bc;
   a.plane_stride = p.plane_stride;
   a.nx = p.nx;
   a.ny = p.ny;
@@ -55,6 +64,7 @@ int launch_typed(const StepLaunch& p) {
   a.omega = static_cast<T>(p.omega);
   const int threads = p.block_threads > 0 ? p.block_threads : 256;
   int tz = a.nzq < threads ? a.nzq : threads;
+  if (p.block_tz > 0 && p.block_tz < tz) tz = p.block_tz;
   int ty = threads / tz;
   if (ty < 1) ty = 1;
   if (ty > p.ny) ty = p.ny;
@@ -84,9 +94,8 @@ int launch_policy(const StepLaunch& p) {
   const int v = pick_vec(p.compute_dtype, p.nz, p.vec);
   if constexpr (sizeof(T) == 4) {
     if (v == 4) return launch_vec<L, T, S, 4, COLL>(p);
-  } else {
-    if (v == 2) return launch_vec<L, T, S, 2, COLL>(p);
   }
+  if (v == 2) return launch_vec<L, T, S, 2, COLL>(p);
   return launch_vec<L, T, S, 1, COLL>(p);
 }
 
