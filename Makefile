@@ -2,10 +2,11 @@
 HIPCC     ?= /opt/rocm/bin/hipcc
 ARCH      ?= gfx950
 CSRC      := xlb_amd/csrc
-OBJDIR    := build/obj
-LIB       := xlb_amd/lib/libxlbhip.so
+OBJDIR    ?= build/obj
+LIB       ?= xlb_amd/lib/libxlbhip.so
 # -ffp-contract=off: fp32/fp64 results are bit-identical to the oracle's operation order
-HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
+EXTRA     ?=
+HIPFLAGS  := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
 SRCS      := api.hip comm.cpp step_d2q9_bgk.hip step_d2q9_kbc.hip step_d3q19_bgk.hip step_d3q27_bgk.hip step_d3q27_kbc.hip
 OBJS      := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(basename $(SRCS))))
 HDRS      := $(wildcard $(CSRC)/*.hpp) include/xlbhip.h

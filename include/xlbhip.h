@@ -94,8 +94,15 @@ int xlbhip_field_create(xlbhip_ctx* ctx, int cardinality, int nx, int ny, int nz
 int xlbhip_field_destroy(xlbhip_field* f);
 int xlbhip_field_fill(xlbhip_field* f, double value);
 int xlbhip_field_copy(xlbhip_field* dst, const xlbhip_field* src);            /* wp.copy, nse_stepper.py:124 */
+/* streaming copy by a plain kernel (4 or 16 bytes per lane): bandwidth yardstick and the
+ * known-byte-count calibration of the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/) */
+int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int bytes_per_lane);
 int xlbhip_field_upload(xlbhip_field* f, const void* host, size_t host_bytes);   /* interior only */
 int xlbhip_field_download(const xlbhip_field* f, void* host, size_t host_bytes); /* interior only; synchronous */
+/* one x-plane of one population, addressed by STORAGE plane (0 .. nx + 2 halo - 1, ghosts included):
+ * host-staged halo transports and tests */
+int xlbhip_field_plane_download(const xlbhip_field* f, int population, int storage_plane, void* host, size_t bytes);
+int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane, const void* host, size_t bytes);
 int xlbhip_field_info(const xlbhip_field* f, int* cardinality, int* nx, int* ny, int* nz, int* dtype, int* halo,
                       uint64_t* plane_stride_elems, void** device_ptr);
 
@@ -152,6 +159,8 @@ int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, co
  * face-crossing populations along the slowest spatial axis). */
 #define XLBHIP_UNIQUE_ID_BYTES 128
 int xlbhip_comm_unique_id(void* out_id_bytes);     /* rank 0; broadcast by the host side */
+/* n_ranks == 1 with a non-NULL id creates a real one-rank RCCL communicator (self send/recv): used to
+ * exercise the RCCL code path on a single GPU; with a NULL id the ghosts are refilled by device copies */
 int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_bytes, int periodic_x);
 int xlbhip_comm_destroy(xlbhip_ctx* ctx);
 /* fill the ghost planes of f from the neighbours (blocking w.r.t. the compute stream order) */

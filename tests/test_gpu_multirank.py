@@ -1,0 +1,47 @@
+"""The HIP slab path beyond one rank, on the one-GPU boxes of this pool:
+  * two ranks sharing device 0 with the host-staged (gloo) halo transport — everything of the
+    multi-rank path except the RCCL calls: per-slab masks from global indices, ghost planes,
+    uneven slabs, periodic ring;
+  * one rank with a REAL RCCL communicator (self send/recv) — the RCCL calls, the communication
+    stream and the interior/edge overlap, minus the wire;
+  * two ranks over RCCL proper: runs when RCCL accepts the device set, skipped on "Duplicate GPU".
+"""
+
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_distributed_gloo import ROOT, free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def torchrun(script, world, **env):
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", script)]
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_two_ranks_one_gpu_host_staged_halo():
+    out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="host")
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "GPU_SLAB_OK" in out.stdout
+
+
+def test_one_rank_real_rccl_self_exchange():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_rccl_self_worker.py")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "RCCL_SELF_OK" in out.stdout
+
+
+def test_two_ranks_rccl():
+    out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="rccl", NCCL_DEBUG="WARN")
+    text = out.stdout + out.stderr
+    if out.returncode != 0 and "Duplicate GPU detected" in text:
+        pytest.skip("RCCL refuses two ranks on one device (one-GPU box)")
+    assert out.returncode == 0, text[-3000:]
+    assert "GPU_SLAB_OK" in out.stdout

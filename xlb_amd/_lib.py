@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxlbhip.so")
+LIB_PATH = os.environ.get("XLBHIP_LIB") or os.path.join(_HERE, "lib", "libxlbhip.so")  # XLBHIP_LIB: A/B builds (tools/)
 
 # element types (include/xlbhip.h)
 F64, F32, F16, U8, BOOL, MISSING = 0, 1, 2, 3, 4, 5
@@ -51,8 +51,11 @@ SIGNATURES = {
     "xlbhip_field_destroy": [_p],
     "xlbhip_field_fill": [_p, _d],
     "xlbhip_field_copy": [_p, _p],
+    "xlbhip_field_copy_kernel": [_p, _p, _i],
     "xlbhip_field_upload": [_p, _p, C.c_size_t],
     "xlbhip_field_download": [_p, _p, C.c_size_t],
+    "xlbhip_field_plane_download": [_p, _i, _i, _p, C.c_size_t],
+    "xlbhip_field_plane_upload": [_p, _i, _i, _p, C.c_size_t],
     "xlbhip_field_info": [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                           C.POINTER(C.c_uint64), _pp],
     "xlbhip_stream": [_p, _i, _p, _p],
@@ -226,6 +229,21 @@ class Field:
 
     def copy_from(self, other):
         check(load().xlbhip_field_copy(self.handle, other.handle))
+        return self
+
+    def get_plane(self, population, storage_plane):
+        """One x-plane (ny, nz) of one population; storage_plane counts the left ghost (if any) as 0."""
+        out = np.empty(self._s3[1:], dtype=self.dtype)
+        check(load().xlbhip_field_plane_download(self.handle, int(population), int(storage_plane), out.ctypes.data, out.nbytes))
+        return out
+
+    def set_plane(self, population, storage_plane, array):
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        assert a.shape == tuple(self._s3[1:])
+        check(load().xlbhip_field_plane_upload(self.handle, int(population), int(storage_plane), a.ctypes.data, a.nbytes))
+
+    def copy_kernel_from(self, other, bytes_per_lane=16):
+        check(load().xlbhip_field_copy_kernel(self.handle, other.handle, int(bytes_per_lane)))
         return self
 
     def info(self):

@@ -113,8 +113,10 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["nt_store"] = 1;         // non-temporal stores in the fused kernel
   c->opts["plane_pad_bytes"] = 4352;  // de-alias the q population planes
   c->opts["block_threads"] = 256;
+  c->opts["xcd_swizzle"] = 0;      // blocks of one row on one XCD (see step_kernel.hpp)
   c->opts["block_tz"] = 0;         // threads along z per block (0 = a whole row when it fits)
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
+  c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
   return 0;
 }
@@ -256,6 +258,24 @@ int xlbhip_field_copy(xlbhip_field* dst, const xlbhip_field* src) {
   return 0;
 }
 
+int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int bytes_per_lane) {
+  XLB_REQUIRE(dst && src, "null field");
+  XLB_REQUIRE(dst->alloc_bytes == src->alloc_bytes && dst != src, "field_copy_kernel: layouts differ");
+  XLB_REQUIRE(bytes_per_lane == 4 || bytes_per_lane == 16, "bytes_per_lane must be 4 or 16");
+  const size_t bytes = src->planes * src->plane_stride * dtype_size(src->dtype);
+  XLB_REQUIRE(bytes % 16 == 0, "field size not a multiple of 16 bytes");
+  hipStream_t st = dst->ctx->stream;
+  if (bytes_per_lane == 4) {
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(k_copy<uint32_t>, blocks_for(n), 256, 0, st, (const uint32_t*)src->data, (uint32_t*)dst->data, n);
+  } else {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(k_copy<u32x4>, blocks_for(n), 256, 0, st, (const u32x4*)src->data, (u32x4*)dst->data, n);
+  }
+  XLB_HIP(hipGetLastError());
+  return 0;
+}
+
 int xlbhip_field_info(const xlbhip_field* f, int* card, int* nx, int* ny, int* nz, int* dtype, int* halo, uint64_t* ps, void** ptr) {
   XLB_REQUIRE(f, "field is null");
   if (card) *card = f->card;
@@ -317,6 +337,32 @@ int xlbhip_field_download(const xlbhip_field* f, void* host, size_t bytes) {
     XLB_HIP(hipMemcpyAsync(static_cast<char*>(host) + (size_t)l * n * es, s, n * es, hipMemcpyDeviceToHost, st));
   }
   XLB_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+int xlbhip_field_plane_download(const xlbhip_field* f, int population, int storage_plane, void* host, size_t bytes) {
+  XLB_REQUIRE(f && host, "null argument");
+  XLB_REQUIRE(f->dtype != XLBHIP_MISSING, "plane access is not defined for the bit-packed missing_mask");
+  XLB_REQUIRE(population >= 0 && population < f->card && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
+              "plane (%d, %d) out of range", population, storage_plane);
+  const size_t es = dtype_size(f->dtype), plane = (size_t)f->ny * f->nz;
+  XLB_REQUIRE(bytes == plane * es, "plane size %zu != %zu", bytes, plane * es);
+  const char* s = static_cast<const char*>(f->data) + ((size_t)population * f->plane_stride + (size_t)storage_plane * plane) * es;
+  XLB_HIP(hipMemcpyAsync(host, s, bytes, hipMemcpyDeviceToHost, f->ctx->stream));
+  XLB_HIP(hipStreamSynchronize(f->ctx->stream));
+  return 0;
+}
+
+int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane, const void* host, size_t bytes) {
+  XLB_REQUIRE(f && host, "null argument");
+  XLB_REQUIRE(f->dtype != XLBHIP_MISSING, "plane access is not defined for the bit-packed missing_mask");
+  XLB_REQUIRE(population >= 0 && population < f->card && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
+              "plane (%d, %d) out of range", population, storage_plane);
+  const size_t es = dtype_size(f->dtype), plane = (size_t)f->ny * f->nz;
+  XLB_REQUIRE(bytes == plane * es, "plane size %zu != %zu", bytes, plane * es);
+  char* d = static_cast<char*>(f->data) + ((size_t)population * f->plane_stride + (size_t)storage_plane * plane) * es;
+  XLB_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, f->ctx->stream));
+  XLB_HIP(hipStreamSynchronize(f->ctx->stream));
   return 0;
 }
 
@@ -574,8 +620,14 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.flags = opt(c, "nt_store", 1) ? 1 : 0;
   p.block_threads = (int)opt(c, "block_threads", 256);
   p.block_tz = (int)opt(c, "block_tz", 0);
+  p.xcd_swizzle = (int)opt(c, "xcd_swizzle", 0);
   p.stream = c->stream;
   if (src->halo == 0) {
+    p.x_begin = 0;
+    p.x_count = src->nx;
+    return launch_any(s, p);
+  }
+  if (opt(c, "external_halo", 0)) {
     p.x_begin = 0;
     p.x_count = src->nx;
     return launch_any(s, p);

@@ -87,7 +87,7 @@ int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t st
   auto ptr = [&](int l, int X) { return static_cast<char*>(f->data) + ((size_t)l * f->plane_stride + (size_t)X * plane) * es; };
   const int nx = f->nx;
   Comm* cm = c->comm;
-  if (!cm || cm->n_ranks == 1) {
+  if (!cm || !cm->comm) {
     if (cm && !cm->periodic) return 0;
     for (int l : right) XLB_HIP(hipMemcpyAsync(ptr(l, 0), ptr(l, nx), bytes, hipMemcpyDeviceToDevice, st));
     for (int l : left) XLB_HIP(hipMemcpyAsync(ptr(l, nx + 1), ptr(l, 1), bytes, hipMemcpyDeviceToDevice, st));
@@ -134,8 +134,8 @@ int xlbhip_comm_init(xlbhip_ctx* c, int rank, int n_ranks, const void* id_bytes,
   cm->rank = rank;
   cm->n_ranks = n_ranks;
   cm->periodic = periodic_x ? 1 : 0;
-  if (n_ranks > 1) {
-    XLB_REQUIRE(id_bytes, "unique id is null");
+  XLB_REQUIRE(n_ranks == 1 || id_bytes, "unique id is null");
+  if (id_bytes) {
     if (int rc = load_rccl()) {
       delete cm;
       return rc;

@@ -240,6 +240,15 @@ __global__ void k_unpack_missing(const uint32_t* bits, uint8_t* bytes, int q, Di
   for (int l = 0; l < q; ++l) bytes[(size_t)l * n + c] = (b >> l) & 1u;
 }
 
+// plain streaming copy, W bytes per lane: the bandwidth yardstick and the byte-count
+// calibration kernel for the FETCH_SIZE / WRITE_SIZE counters (known traffic: n bytes each way)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <class V>
+__global__ void k_copy(const V* __restrict__ src, V* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) __builtin_nontemporal_store(src[i], dst + i);
+}
+
 template <class E>
 __global__ void k_fill(E* p, size_t n, E v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -21,6 +21,10 @@
 #pragma once
 #include "cell.hpp"
 
+#ifndef XLB_LB1
+#define XLB_LB1 256  // launch bound of the one-cell-per-thread variants
+#endif
+
 namespace xlb {
 
 // kinds as the kernel sees them
@@ -43,6 +47,7 @@ struct StepArgs {
   int halo;             // ghost planes per side (0: periodic wrap in x done here)
   int x_begin;          // first interior x plane updated by this launch
   int nzq;              // nz / VEC
+  int xcd_swizzle;      // remap blockIdx so that the blocks of one row share an XCD (needs gridDim.y % 8 == 0)
   T omega;
 };
 
@@ -123,11 +128,22 @@ __device__ __forceinline__ unsigned kind_of(const StepArgs<T, S>& a, unsigned id
 
 // FLAGS bit 0: non-temporal stores
 template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
-__global__ void __launch_bounds__(256) k_step(const StepArgs<T, S> a) {
+__global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArgs<T, S> a) {
   constexpr int Q = L::Q;
   constexpr unsigned ES = sizeof(S);
-  const int zq = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  // Blocks are dealt round-robin over the 8 XCDs (b and b + 8 share an L2).  With xcd_swizzle the
+  // blockIdx.x that cover ONE row are spaced 8 apart in dispatch order, so the cache line that a
+  // z-shifted load shares with the neighbouring block of the same row is served by the same L2.
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_swizzle) {
+    const unsigned gx = gridDim.x;                    // blocks per row
+    const unsigned lin = blockIdx.y * gx + blockIdx.x;  // dispatch order inside the x-plane
+    const unsigned grp = lin / (8u * gx), r = lin % (8u * gx);
+    by = grp * 8u + (r % 8u);
+    bx = r / 8u;
+  }
+  const int zq = bx * blockDim.x + threadIdx.x;
+  const int y = by * blockDim.y + threadIdx.y;
   if (zq >= a.nzq || y >= a.ny) return;
   const int x = a.x_begin + blockIdx.z;  // block-uniform
   const int z0 = zq * VEC;

@@ -26,6 +26,7 @@ struct StepLaunch {
   int flags;   // bit 0: non-temporal stores
   int block_threads;  // 0 = default (256)
   int block_tz;       // threads along z per block, 0 = as many as fit
+  int xcd_swizzle;
   hipStream_t stream;
 };
 
@@ -70,6 +71,8 @@ int launch_typed(const StepLaunch& p) {
   if (ty > p.ny) ty = p.ny;
   dim3 block(tz, ty, 1);
   dim3 grid((a.nzq + tz - 1) / tz, (p.ny + ty - 1) / ty, p.x_count);
+  XLB_REQUIRE(threads <= (VEC == 1 ? XLB_LB1 : 256), "block_threads %d exceeds the kernel's launch bound", threads);
+  a.xcd_swizzle = (p.xcd_swizzle && grid.x > 1 && grid.y % 8 == 0) ? 1 : 0;
   XLB_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "grid too large: ny/ty=%u x_count=%u", grid.y, grid.z);
   hipLaunchKernelGGL((k_step<L, T, S, VEC, COLL, HASBC, FLAGS>), grid, block, 0, p.stream, a);
   XLB_HIP(hipGetLastError());

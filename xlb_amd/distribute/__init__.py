@@ -3,6 +3,8 @@ from .distribute import (
     distribute as distribute,
     gather_field as gather_field,
     SlabPlan as SlabPlan,
+    HostStagedHalo as HostStagedHalo,
+    all_reduce_sum as all_reduce_sum,
     barrier as barrier,
     all_reduce_max as all_reduce_max,
 )

@@ -28,7 +28,7 @@ def _env_int(name, default):
     return int(v) if v else default
 
 
-def init_process_group(periodic_x=True, init_device_comm=True):
+def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl"):
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
     (as set by ``python -m torch.distributed.run``).  Single-process jobs return (0, 1)
     without importing torch."""
@@ -44,11 +44,48 @@ def init_process_group(periodic_x=True, init_device_comm=True):
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     _state["dist"] = dist
     if init_device_comm:
-        ctx = get_context()  # device = LOCAL_RANK (default_config._pick_device)
-        box = [_lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(rank, world, box[0], periodic_x=periodic_x)
+        ctx = get_context()  # device = XLB_HIP_DEVICE or LOCAL_RANK (default_config._pick_device)
+        if transport == "rccl":
+            box = [_lib.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(rank, world, box[0], periodic_x=periodic_x)
+        elif transport == "host":
+            # debugging transport: ghost planes travel through host memory and gloo (HostStagedHalo);
+            # lets several ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected")
+            ctx.rank, ctx.n_ranks = rank, world
+            ctx.set_option("external_halo", 1)
+        else:
+            raise ValueError(f"unknown halo transport {transport!r}")
     return rank, world
+
+
+class HostStagedHalo:
+    """Ring halo exchange through host memory + gloo, same messages as csrc/comm.cpp (SlabPlan).
+    A debugging transport (orders of magnitude slower than RCCL over xGMI); used with the
+    ``external_halo`` option: call ``exchange(f)`` before every step."""
+
+    def __init__(self, grid, velocity_set, periodic=True):
+        self.plan = SlabPlan(grid.shape[0], grid.rank, grid.n_ranks, velocity_set._c[0], periodic=periodic)
+
+    def exchange(self, f):
+        import torch
+
+        dist = _state["dist"]
+        reqs, recvs = [], []
+        for _, pops, send_plane, ghost_plane, send_peer, recv_peer in self.plan.messages():
+            if send_peer is not None:
+                buf = torch.from_numpy(np.stack([f.get_plane(int(l), send_plane) for l in pops]))
+                reqs.append(dist.isend(buf, dst=send_peer))
+            if recv_peer is not None:
+                rbuf = torch.from_numpy(np.empty((len(pops),) + tuple(f._s3[1:]), dtype=f.dtype))
+                reqs.append(dist.irecv(rbuf, src=recv_peer))
+                recvs.append((pops, ghost_plane, rbuf))
+        for r in reqs:
+            r.wait()
+        for pops, ghost_plane, rbuf in recvs:
+            arr = rbuf.numpy()
+            for i, l in enumerate(pops):
+                f.set_plane(int(l), ghost_plane, arr[i])
 
 
 def rank():
