@@ -3,7 +3,7 @@ oracle cannot run 512^3 in seconds:
   * tiling: a periodic domain initialised with a 16^3-periodic pattern must stay the tiling of
     the 16^3 oracle solution, bit for bit (exercises every address computation at full size);
   * mass conservation in the periodic box;
-  * cavity at full size: mirror symmetry in y of rho / u_x / u_z, antisymmetry of u_y, and
+  * cavity at full size: mirror symmetry in y of rho / u_x / u_z, antisymmetry of u_y (to rounding), and
     agreement with the committed 16^3 golden masks' structure (counts scale as 6 faces).
 """
 
@@ -58,8 +58,10 @@ def test_cavity_512_symmetry(walls_cls):
     f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, 20)
     rho, u = hip_macroscopic(f_0, grid, vs, pp)
     assert np.isfinite(rho).all() and np.isfinite(u).all()
-    # lid moves along +x: the flow is mirror-symmetric about the y mid-plane
-    assert np.array_equal(rho, rho[:, :, ::-1, :])
-    assert np.array_equal(u[0], u[0][:, ::-1, :]) and np.array_equal(u[2], u[2][:, ::-1, :])
-    assert np.array_equal(u[1], -u[1][:, ::-1, :])
+    # lid moves along +x: the flow is mirror-symmetric about the y mid-plane — to rounding only, because the
+    # moment sums run in a fixed direction order that the mirror image permutes
+    sym = 2e-6
+    assert np.abs(rho - rho[:, :, ::-1, :]).max() <= sym
+    assert np.abs(u[0] - u[0][:, ::-1, :]).max() <= sym and np.abs(u[2] - u[2][:, ::-1, :]).max() <= sym
+    assert np.abs(u[1] + u[1][:, ::-1, :]).max() <= sym
     assert float(np.abs(u[0]).max()) > 1e-3  # the lid actually drives the flow
