@@ -58,13 +58,28 @@ def cavity_bcs(grid, walls_cls, EquilibriumBC):
     return [EquilibriumBC(rho=1.0, u=(0.02, 0.0, 0.0), indices=lid), walls_cls(indices=walls)]
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "").strip()
+    if env.isdigit():
+        n = min(n, int(env))
+    return n
+
+
 def cpu_baseline(args):
     """The C restatement of the same step (oracle/lbm_ref.c, OpenMP) timed on this host's cores on a
     bounded sample of the same workload.  Checker code timed as a baseline — never the product."""
     from oracle import lbm_ref, xlb_numpy as orc
 
     n = args.cpu_baseline_size
-    threads = len(os.sched_getaffinity(0))
+    threads = host_cores()
     lbm_ref.set_threads(threads)
     lat = orc.Lattice(args.lattice)
     if args.workload == "periodic":
@@ -156,6 +171,18 @@ def main():
     elapsed = xdist.all_reduce_max(time.perf_counter() - t0)
     dev_ms = xdist.all_reduce_max(dev_ms)
 
+    # streaming-copy yardstick on the same device and buffers (after the timed region; f_1 is scratch now)
+    copy_gbs = None
+    if world == 1:
+        f_1.copy_kernel_from(f_0, 16)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            f_1.copy_kernel_from(f_0, 16)
+        ctx.sync()
+        info = f_0.info()
+        copy_gbs = 2 * info["plane_stride"] * vs.q * pp.store_precision.np_dtype(0).itemsize * 5 / (time.perf_counter() - t1) / 1e9
+
     cells_total = float(n) ** 3 * world
     mlups = cells_total * args.steps / elapsed / 1e6
     s_bytes = pp.store_precision.np_dtype(0).itemsize
@@ -194,6 +221,7 @@ def main():
             "kernel": kernel,
             "kernel_ms": round(step_ms, 4),
             "algorithmic_bytes_per_update": b_alg,
+            "copy_yardstick_gbs": None if copy_gbs is None else round(copy_gbs, 1),
         },
     }
     if world == 1 and args.cpu_baseline_seconds > 0:

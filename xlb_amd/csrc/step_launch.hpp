@@ -31,12 +31,13 @@ struct StepLaunch {
 };
 
 // which (T, S, VEC) combinations exist: fp32 compute -> VEC in {1, 2, 4}; fp64 compute -> {1, 2}
-inline int pick_vec(int compute_dtype, int nz, int requested) {
+inline int pick_vec(int compute_dtype, int nz, int requested, int collision) {
   // Measured on MI355X (profiles/r01_sweeps.md): one cell per thread wins for D3Q19 fp32 at 512^3
   // (44-60 VGPRs -> 8 waves/SIMD; 75.9 % of the HBM peak vs 74.5 % for VEC=2 and 72.9 % for VEC=4),
-  // so "auto" (0) means 1.  Wider variants stay selectable through the "vec" option.
+  // so "auto" (0) means 1 — except fp64 KBC, which is VALU/register-bound and prefers 2.
+  // Wider variants stay selectable through the "vec" option.
   const int vmax = (compute_dtype == XLBHIP_F32) ? 4 : 2;
-  int v = requested > 0 ? requested : 1;
+  int v = requested > 0 ? requested : ((collision == XLBHIP_KBC && compute_dtype == XLBHIP_F64) ? 2 : 1);
   if (v > vmax) v = vmax;
   if (v == 3) v = 2;
   if (nz % v != 0) v = 1;
@@ -94,7 +95,7 @@ int launch_vec(const StepLaunch& p) {
 
 template <class L, class T, class S, int COLL>
 int launch_policy(const StepLaunch& p) {
-  const int v = pick_vec(p.compute_dtype, p.nz, p.vec);
+  const int v = pick_vec(p.compute_dtype, p.nz, p.vec, COLL);
   if constexpr (sizeof(T) == 4) {
     if (v == 4) return launch_vec<L, T, S, 4, COLL>(p);
   }
