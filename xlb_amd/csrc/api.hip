@@ -111,6 +111,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   // defaults of the tuning knobs
   c->opts["vec"] = 0;              // cells per thread: 0 = auto (1), or 1 / 2 / 4
   c->opts["nt_store"] = 1;         // non-temporal stores in the fused kernel
+  c->opts["nt_load"] = 1;          // 1: nt loads for the c_z == 0 directions (+1.8 %), 3: for all (slower; D3Q19 BGK tuning variants only)
   c->opts["plane_pad_bytes"] = 4352;  // de-alias the q population planes
   c->opts["block_threads"] = 256;
   c->opts["xcd_swizzle"] = 0;      // blocks of one row on one XCD (see step_kernel.hpp)
@@ -617,7 +618,7 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.store_dtype = s->sdt;
   p.vec = (int)opt(c, "vec", 0);
   p.has_bc = p.bc != nullptr;
-  p.flags = opt(c, "nt_store", 1) ? 1 : 0;
+  p.flags = (opt(c, "nt_store", 1) ? 1 : 0) | (int)(opt(c, "nt_load", 0) << 1);
   p.block_threads = (int)opt(c, "block_threads", 256);
   p.block_tz = (int)opt(c, "block_tz", 0);
   p.xcd_swizzle = (int)opt(c, "xcd_swizzle", 0);

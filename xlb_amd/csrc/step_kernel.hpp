@@ -62,13 +62,20 @@ template <class S>
 __device__ __forceinline__ S ld(const S* base, unsigned boff) {
   return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + boff);
 }
-template <class S, int VEC>
+template <class S, int VEC, bool NT = false>
 __device__ __forceinline__ void ld_aligned(const S* base, unsigned boff, S (&out)[VEC]) {
   if constexpr (VEC == 1) {
-    out[0] = ld(base, boff);
+    if constexpr (NT)
+      out[0] = __builtin_nontemporal_load(reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + boff));
+    else
+      out[0] = ld(base, boff);
   } else {
     typedef typename VecOf<S, VEC>::aligned V;
-    const V v = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + boff);
+    V v;
+    if constexpr (NT)
+      v = __builtin_nontemporal_load(reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + boff));
+    else
+      v = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + boff);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) out[k] = v[k];
   }
@@ -126,7 +133,8 @@ __device__ __forceinline__ unsigned kind_of(const StepArgs<T, S>& a, unsigned id
   return kind;
 }
 
-// FLAGS bit 0: non-temporal stores
+// FLAGS bit 0: non-temporal stores; bit 1: non-temporal loads of the c_z == 0 directions;
+// bit 2: non-temporal loads of the z-shifted directions too (VEC == 1)
 template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
 __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArgs<T, S> a) {
   constexpr int Q = L::Q;
@@ -181,11 +189,14 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
     const unsigned yb = Yb[cy + 1];
     S v[VEC];
     if constexpr (cz == 0) {
-      ld_aligned<S, VEC>(row, yb + zb, v);
+      ld_aligned<S, VEC, (FLAGS & 2) != 0>(row, yb + zb, v);
     } else if constexpr (VEC == 1) {
       int zs = z0 - cz;
       zs = zs < 0 ? nz - 1 : (zs == nz ? 0 : zs);
-      v[0] = ld(row, yb + (unsigned)zs * ES);
+      if constexpr ((FLAGS & 4) != 0)
+        v[0] = __builtin_nontemporal_load(reinterpret_cast<const S*>(reinterpret_cast<const char*>(row) + (yb + (unsigned)zs * ES)));
+      else
+        v[0] = ld(row, yb + (unsigned)zs * ES);
     } else if constexpr (cz == 1) {
       // need z0-1 .. z0+VEC-2 ; at the row start z0-1 wraps to nz-1
       S t[VEC];

@@ -65,7 +65,14 @@ int launch_typed(const StepLaunch& p) {
   a.nzq = p.nz / VEC;
   a.omega = static_cast<T>(p.omega);
   const int threads = p.block_threads > 0 ? p.block_threads : 256;
-  int tz = a.nzq < threads ? a.nzq : threads;
+  // threads along z: split a row into equal chunks of whole waves (nz = 384 -> 2 x 192, not 256 + 128)
+  int tz = a.nzq;
+  if (tz > threads) {
+    const int chunks = (a.nzq + threads - 1) / threads;
+    tz = (a.nzq + chunks - 1) / chunks;
+    tz = (tz + 63) / 64 * 64;
+    if (tz > threads) tz = threads;
+  }
   if (p.block_tz > 0 && p.block_tz < tz) tz = p.block_tz;
   int ty = threads / tz;
   if (ty < 1) ty = 1;
@@ -80,17 +87,25 @@ int launch_typed(const StepLaunch& p) {
   return 0;
 }
 
+template <class L, class T, class S, int VEC, int COLL, bool HASBC>
+int launch_flags(const StepLaunch& p) {
+#ifdef XLB_TUNE_VARIANTS
+  switch (p.flags & 7) {
+    case 0: return launch_typed<L, T, S, VEC, COLL, HASBC, 0>(p);
+    case 1: return launch_typed<L, T, S, VEC, COLL, HASBC, 1>(p);
+    case 3: return launch_typed<L, T, S, VEC, COLL, HASBC, 3>(p);
+    case 7: return launch_typed<L, T, S, VEC, COLL, HASBC, 7>(p);
+    default: XLB_FAIL("flag combination %d not instantiated", p.flags);
+  }
+#else
+  return (p.flags & 2) ? launch_typed<L, T, S, VEC, COLL, HASBC, 3>(p) : launch_typed<L, T, S, VEC, COLL, HASBC, 1>(p);
+#endif
+}
+
 template <class L, class T, class S, int VEC, int COLL>
 int launch_vec(const StepLaunch& p) {
-  const bool nt = (p.flags & 1) != 0;
-#ifdef XLB_TUNE_VARIANTS
-  if (p.has_bc) return nt ? launch_typed<L, T, S, VEC, COLL, true, 1>(p) : launch_typed<L, T, S, VEC, COLL, true, 0>(p);
-  return nt ? launch_typed<L, T, S, VEC, COLL, false, 1>(p) : launch_typed<L, T, S, VEC, COLL, false, 0>(p);
-#else
-  (void)nt;
-  if (p.has_bc) return launch_typed<L, T, S, VEC, COLL, true, 1>(p);
-  return launch_typed<L, T, S, VEC, COLL, false, 1>(p);
-#endif
+  if (p.has_bc) return launch_flags<L, T, S, VEC, COLL, true>(p);
+  return launch_flags<L, T, S, VEC, COLL, false>(p);
 }
 
 template <class L, class T, class S, int COLL>
