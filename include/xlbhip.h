@@ -56,7 +56,13 @@ enum {
   XLBHIP_BC_EQUILIBRIUM = 1,  /* bc_equilibrium.py:72-80   (post-streaming) */
   XLBHIP_BC_HALFWAY_BB = 2,   /* bc_halfway_bounce_back.py:116-134 (post-streaming) */
   XLBHIP_BC_FULLWAY_BB = 3,   /* bc_fullway_bounce_back.py:50-56   (post-collision) */
-  XLBHIP_BC_DO_NOTHING = 4    /* bc_do_nothing.py:50-54    (post-streaming) */
+  XLBHIP_BC_DO_NOTHING = 4,   /* bc_do_nothing.py:50-54    (post-streaming) */
+  /* SURVEY.md section 8f rank 1 — inlet/outlet family with CONSTANT prescribed values (JAX semantics:
+   * the value lives in the BC object, bc_zouhe.py:120-121, not in the f_1 aux encoding) */
+  XLBHIP_BC_ZOUHE_VELOCITY = 5,        /* bc_zouhe.py:218-304, values[0..2] = velocity (3-component internal form) */
+  XLBHIP_BC_ZOUHE_PRESSURE = 6,        /* values[0] = density */
+  XLBHIP_BC_REGULARIZED_VELOCITY = 7,  /* bc_regularized.py:78-137 */
+  XLBHIP_BC_REGULARIZED_PRESSURE = 8
 };
 
 /* One boundary condition as the stepper sees it.  `values` holds, in COMPUTE

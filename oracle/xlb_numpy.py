@@ -39,6 +39,12 @@ KIND_EQUILIBRIUM = "equilibrium"
 KIND_HALFWAY_BB = "halfway_bounce_back"
 KIND_FULLWAY_BB = "fullway_bounce_back"
 KIND_DO_NOTHING = "do_nothing"
+# SURVEY.md section 8f rank 1 ("next"): inlet / outlet family with constant prescribed values
+KIND_ZOUHE_VELOCITY = "zouhe_velocity"
+KIND_ZOUHE_PRESSURE = "zouhe_pressure"
+KIND_REGULARIZED_VELOCITY = "regularized_velocity"
+KIND_REGULARIZED_PRESSURE = "regularized_pressure"
+ZOUHE_KINDS = (KIND_ZOUHE_VELOCITY, KIND_ZOUHE_PRESSURE, KIND_REGULARIZED_VELOCITY, KIND_REGULARIZED_PRESSURE)
 
 
 # ----------------------------------------------------------------------------
@@ -297,8 +303,9 @@ class BC:
     boundary_condition_registry.py:16-27: ids are handed out by the caller here
     (the oracle has no process-global registry)."""
 
-    def __init__(self, kind, bc_id, indices, rho=None, u=None, u_wall=None):
+    def __init__(self, kind, bc_id, indices, rho=None, u=None, u_wall=None, prescribed=None):
         self.kind = kind
+        self.prescribed = prescribed  # ZouHe / Regularized: velocity vector or density scalar
         self.id = int(bc_id)
         self.indices = None if indices is None else np.asarray(indices, dtype=np.int64)
         self.rho = rho
@@ -306,7 +313,7 @@ class BC:
         self.u_wall = u_wall
         self.step = STEP_COLLISION if kind == KIND_FULLWAY_BB else STEP_STREAMING
         # bc_halfway_bounce_back.py:60 sets needs_padding; others keep the base False
-        self.needs_padding = kind == KIND_HALFWAY_BB
+        self.needs_padding = kind == KIND_HALFWAY_BB or kind in ZOUHE_KINDS  # bc_zouhe.py:146
 
     def pad_indices(self, lat):
         """boundary_condition.py:123-136"""
@@ -349,7 +356,67 @@ def apply_bc(bc, f_pre, f_post, bc_mask, missing_mask, lat, policy):
         return np.where(_bcast(boundary, lat.q), f_pre[lat.opp], f_post)
     if bc.kind == KIND_DO_NOTHING:
         return np.where(_bcast(boundary, lat.q), f_pre, f_post)
+    if bc.kind in ZOUHE_KINDS:
+        return _zouhe(bc, f_post, boundary, missing_mask.astype(bool), lat, policy)
     raise ValueError(bc.kind)
+
+
+def _seq_sum(terms):
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = acc + t
+    return acc
+
+
+def _zouhe(bc, f_post, boundary, missing, lat, policy):
+    """Zou-He (bc_zouhe.py:166-304) and Regularized (bc_regularized.py:78-137) with a CONSTANT
+    prescribed normal velocity vector or density; sums are sequential in direction order."""
+    T = f_post.dtype.type
+    S = store_dtype(policy)
+    q, d = lat.q, lat.d
+    opp = lat.opp
+    # bc_zouhe.py:166-177
+    known = missing[opp]
+    middle = ~(missing | known)
+    normals = [-_seq_sum([int(lat.c[a, l]) * missing[l].astype(np.int32) for l in lat.main]) for a in range(d)]
+    fsum = _seq_sum([np.where(middle[l], f_post[l], T(0)) for l in range(q)]) + T(2.0) * _seq_sum(
+        [np.where(known[l], f_post[l], T(0)) for l in range(q)]
+    )
+    velocity = bc.kind in (KIND_ZOUHE_VELOCITY, KIND_REGULARIZED_VELOCITY)
+    if velocity:
+        pv = np.asarray(bc.prescribed, dtype=np.float64).astype(S).astype(T)  # bc_zouhe.py:155-156
+        vel = [np.full(f_post.shape[1:], pv[a], dtype=T) for a in range(d)]
+        unormal = _seq_sum([normals[a].astype(T) * vel[a] for a in range(d)])  # :263
+        rho = fsum / (T(1.0) + unormal)  # :265
+    else:
+        rho = np.full(f_post.shape[1:], T(S(bc.prescribed)), dtype=T)
+        unormal = T(-1.0) + fsum / rho  # :250
+        vel = [unormal * normals[a].astype(T) for a in range(d)]  # :253
+    feq = equilibrium(rho[None], np.stack(vel), lat, T)
+    # bounceback_nonequilibrium, :280-288
+    fknown = (f_post[opp] + feq) - feq[opp]
+    fbd = np.where(missing, fknown, f_post)
+    if bc.kind in (KIND_REGULARIZED_VELOCITY, KIND_REGULARIZED_PRESSURE):
+        # regularize_fpop, bc_regularized.py:78-114; Qi = cc - cs^2 I with doubled off-diagonals (velocity_set.py:139-153)
+        fneq = fbd - feq
+        pi = second_moment(fneq, lat)
+        qi = lat.cc.copy()
+        k = 0
+        for a in range(d):
+            for b in range(a, d):
+                if a == b:
+                    qi[:, k] -= 1.0 / 3.0
+                else:
+                    qi[:, k] *= 2.0
+                k += 1
+        qi = qi.astype(T)
+        w = lat.w.astype(T)
+        out = np.empty_like(fbd)
+        for l in range(q):
+            qp = _seq_sum([qi[l, kk] * pi[kk] for kk in range(pi.shape[0])])
+            out[l] = feq[l] + (T(9.0 / 2.0) * w[l]) * qp
+        fbd = out
+    return np.where(_bcast(boundary, q), fbd, f_post)
 
 
 def are_indices_in_interior(indices, shape):

@@ -1,0 +1,97 @@
+"""Zou-He / Regularized inlet-outlet BCs on the HIP backend vs the oracle.
+No reference test pins these BCs ("parity unpinned by the reference"): the oracle follows
+bc_zouhe.py:166-304 and bc_regularized.py:78-137 line by line."""
+
+import numpy as np
+import pytest
+
+from oracle import xlb_numpy as orc
+from xlb_amd.grid import grid_factory
+from xlb_amd.helper import create_nse_fields
+from xlb_amd.operator.boundary_condition import HalfwayBounceBackBC, RegularizedBC, ZouHeBC
+from xlb_amd.operator.boundary_masker import IndicesBoundaryMasker
+from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
+
+from _util import init_hip, max_ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("D2Q9", (24, 12), "FP32FP32", "BGK"), ("D3Q19", (16, 8, 12), "FP32FP32", "BGK"), ("D3Q27", (10, 6, 8), "FP32FP32", "KBC"),
+         ("D3Q19", (8, 6, 8), "FP64FP64", "BGK"), ("D2Q9", (16, 10), "FP64FP32", "KBC")]
+NAMES = {(ZouHeBC, "velocity"): orc.KIND_ZOUHE_VELOCITY, (ZouHeBC, "pressure"): orc.KIND_ZOUHE_PRESSURE,
+         (RegularizedBC, "velocity"): orc.KIND_REGULARIZED_VELOCITY, (RegularizedBC, "pressure"): orc.KIND_REGULARIZED_PRESSURE}
+
+
+def channel(lattice, shape, policy, cls):
+    vs, pp = init_hip(lattice, policy)
+    lat = orc.Lattice(lattice)
+    d = lat.d
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    faces = ["bottom", "top"] + (["front", "back"] if d == 3 else [])
+    walls = [sum((box[f][i] for f in faces), []) for i in range(d)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    u_in = (0.03,) + (0.0,) * (d - 1)
+    b_in = cls("velocity", prescribed_value=u_in, indices=box_ne["left"])
+    b_out = cls("pressure", prescribed_value=1.0, indices=box_ne["right"])
+    b_w = HalfwayBounceBackBC(indices=walls)
+    obcs = [orc.BC(NAMES[(cls, "velocity")], b_in.id, box_ne["left"], prescribed=u_in),
+            orc.BC(NAMES[(cls, "pressure")], b_out.id, box_ne["right"], prescribed=1.0), orc.BC(orc.KIND_HALFWAY_BB, b_w.id, walls)]
+    return grid, [b_in, b_out, b_w], lat, obcs
+
+
+@pytest.mark.parametrize("cls", [ZouHeBC, RegularizedBC])
+@pytest.mark.parametrize("lattice,shape,policy,collision", CASES)
+def test_channel_flow_vs_oracle(lattice, shape, policy, collision, cls):
+    grid, bcs, lat, obcs = channel(lattice, shape, policy, cls)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type=collision)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    steps = 25
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, steps)
+    with np.errstate(all="ignore"):
+        exp = orc.run(orc.initialize_eq(shape, lat, policy), o_bm, o_mm, obcs, 1.3, lat, steps, policy, collision)
+    out = f_0.numpy()
+    tol = 1e-6 if policy != "FP64FP64" else 1e-12
+    assert np.abs(out.astype(np.float64) - exp.astype(np.float64)).max() <= tol
+    assert np.array_equal(out, exp), f"not bit-exact: max ulp {max_ulp_diff(out, exp)}"
+    rho, u = orc.macroscopic(out.astype(orc.compute_dtype(policy)), lat)
+    assert float(u[0].max()) > 0.02  # the inlet drives a flow
+
+
+@pytest.mark.parametrize("cls", [ZouHeBC, RegularizedBC])
+@pytest.mark.parametrize("lattice,shape", [("D2Q9", (20, 14)), ("D3Q19", (10, 8, 6))])
+def test_standalone_operator_vs_oracle(lattice, shape, cls):
+    """bc(f_pre, f_post, bc_mask, missing_mask) as a stand-alone operator on random populations."""
+    vs, pp = init_hip(lattice)
+    lat = orc.Lattice(lattice)
+    d = lat.d
+    rng = np.random.default_rng(6)
+    a_post = (lat.w.astype(np.float32).reshape((-1,) + (1,) * d) * (1.0 + 0.1 * rng.random((lat.q,) + shape, dtype=np.float32))).astype(np.float32)
+    for bc_type, value in (("velocity", (0.02,) + (0.0,) * (d - 1)), ("pressure", 1.02)):
+        grid, f_0, f_1, missing_mask, bc_mask = create_nse_fields(shape)
+        idx = grid.bounding_box_indices(remove_edges=True)["left"]
+        bc = cls(bc_type, prescribed_value=value, indices=idx)
+        bc_mask, missing_mask = IndicesBoundaryMasker(grid=grid)([bc], bc_mask, missing_mask)
+        f_pre = grid.create_field(vs.q)
+        f_post = grid.create_field(vs.q).assign(a_post)
+        out = bc(f_pre, f_post, bc_mask, missing_mask).numpy()
+        obc = orc.BC(NAMES[(cls, bc_type)], bc.id, idx, prescribed=value)
+        o_bm, o_mm = orc.build_masks(shape, lat, [obc])
+        with np.errstate(all="ignore"):
+            exp = orc.apply_bc(obc, np.zeros_like(a_post), a_post, o_bm, o_mm, lat, "FP32FP32")
+        assert np.array_equal(out, exp), (cls.__name__, bc_type, max_ulp_diff(out, exp))
+
+
+def test_argument_validation():
+    init_hip("D3Q19")
+    with pytest.raises(AssertionError):
+        ZouHeBC("temperature", prescribed_value=1.0, indices=[[0], [0], [0]])
+    with pytest.raises(ValueError):
+        ZouHeBC("velocity", prescribed_value=(0.1, 0.1, 0.0), indices=[[0], [0], [0]])  # only normal values
+    with pytest.raises(ValueError):
+        ZouHeBC("pressure", prescribed_value=(1.0, 0.0, 0.0), indices=[[0], [0], [0]])
+    with pytest.raises(NotImplementedError):
+        RegularizedBC("velocity", profile=lambda: None, indices=[[0], [0], [0]])

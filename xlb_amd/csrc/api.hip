@@ -464,9 +464,9 @@ int xlbhip_apply_bc(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* b
   XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_post), "bc: bad bc_mask field");
   XLB_REQUIRE(same_grid(f_pre, f_post), "bc: grids differ");
   XLB_REQUIRE(bc->id >= 1 && bc->id <= 255, "bc id %d out of range", bc->id);
-  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_DO_NOTHING, "unknown bc kind %d", bc->kind);
-  if (bc->kind == XLBHIP_BC_HALFWAY_BB)
-    XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_post), "bc: halfway bounce-back needs a missing_mask field");
+  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_REGULARIZED_PRESSURE, "unknown bc kind %d", bc->kind);
+  if (bc->kind == XLBHIP_BC_HALFWAY_BB || bc->kind >= XLBHIP_BC_ZOUHE_VELOCITY)
+    XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_post), "bc: this boundary condition needs a missing_mask field");
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
   BcValues vals;
   std::memcpy(vals.v, bc->values, sizeof(vals.v));
@@ -559,6 +559,7 @@ struct xlbhip_stepper {
   int lattice = 0, collision = 0, cdt = 0, sdt = 0;
   int n_bc = 0;
   bool needs_missing = false;
+  bool extended_bcs = false;
   uint8_t* tab_kind = nullptr;  // device [256]
   unsigned long long ids_packed = 0;
   unsigned kinds_packed = 0;
@@ -617,7 +618,7 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.compute_dtype = s->cdt;
   p.store_dtype = s->sdt;
   p.vec = (int)opt(c, "vec", 0);
-  p.has_bc = p.bc != nullptr;
+  p.has_bc = p.bc != nullptr ? (s->extended_bcs ? 2 : 1) : 0;
   p.flags = (opt(c, "nt_store", 1) ? 1 : 0) | (int)(opt(c, "nt_load", 0) << 1);
   p.block_threads = (int)opt(c, "block_threads", 256);
   p.block_tz = (int)opt(c, "block_tz", 0);
@@ -673,12 +674,13 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   std::vector<uint8_t> kind(256, 0);
   const int q = lattice_q(lattice);
   std::vector<double> vals(256 * 27, 0.0);
-  bool needs_missing = false;
+  bool needs_missing = false, extended = false;
   for (int i = 0; i < n_bc; ++i) {
     const xlbhip_bc_desc& b = bcs[i];
     XLB_REQUIRE(b.id >= 1 && b.id <= 255, "bc id %d out of range 1..255", b.id);
-    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_DO_NOTHING, "unknown bc kind %d", b.kind);
+    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_REGULARIZED_PRESSURE, "unknown bc kind %d", b.kind);
     XLB_REQUIRE(kind[b.id] == 0, "bc id %d used twice", b.id);
+    if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY) extended = needs_missing = true;
     kind[b.id] = (uint8_t)b.kind;
     for (int l = 0; l < q; ++l) vals[b.id * 27 + l] = b.values[l];
     if (b.kind == XLBHIP_BC_HALFWAY_BB) needs_missing = true;
@@ -698,6 +700,7 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   s->sdt = sdt;
   s->n_bc = n_bc;
   s->needs_missing = needs_missing;
+  s->extended_bcs = extended;
   s->ids_packed = ids_packed;
   s->kinds_packed = kinds_packed;
   XLB_HIP(hipMalloc(&s->tab_kind, 256));

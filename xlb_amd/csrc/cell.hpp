@@ -273,6 +273,111 @@ __device__ __forceinline__ void kbc_fused(T (&f)[L::Q], T rho, const T (&u_in)[3
   });
 }
 
+// ---- Zou-He / Regularized boundary cell (bc_zouhe.py:166-304, bc_regularized.py:78-137) -------
+template <class L>
+constexpr bool is_main(int l) {
+  return iabs(L::c(0, l)) + iabs(L::c(1, l)) + iabs(L::c(2, l)) == 1;
+}
+// Qi = cc - cs^2 I on the diagonal components, 2 cc off the diagonal (velocity_set.py:139-153)
+template <class L>
+constexpr double qi(int l, int k) {
+  int n = 0;
+  for (int a = 0; a < L::D; ++a)
+    for (int b = a; b < L::D; ++b) {
+      if (n == k) return a == b ? double(cc<L>(l, k)) - 1.0 / 3.0 : double(cc<L>(l, k)) * 2.0;
+      ++n;
+    }
+  return 0.0;
+}
+
+// f: post-streaming populations of the cell (updated in place); m: missing bit-set;
+// val: prescribed velocity (val[0..2], internal 3-component form) or density (val[0]).
+template <class L, class T>
+__device__ __forceinline__ void zouhe_cell(T (&f)[L::Q], unsigned m, const T* val, bool velocity, bool regularized) {
+  constexpr int Q = L::Q;
+  // known = missing[opp], middle = !(missing | known); normals = -sum_main c * missing
+  int nrm[3] = {0, 0, 0};
+  T s1 = T(0), s2 = T(0);
+  static_for<Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const bool mis = (m >> l) & 1u;
+    const bool known = (m >> opp<L>(l)) & 1u;
+    const bool middle = !(mis || known);
+    if constexpr (is_main<L>(l)) {
+      static_for<3>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        if constexpr (L::c(a, l) != 0) nrm[a] = nrm[a] - L::c(a, l) * (mis ? 1 : 0);
+      });
+    }
+    const T t1 = middle ? f[l] : T(0);
+    const T t2 = known ? f[l] : T(0);
+    if constexpr (l == 0) {
+      s1 = t1;
+      s2 = t2;
+    } else {
+      s1 = s1 + t1;
+      s2 = s2 + t2;
+    }
+  });
+  const T fsum = s1 + T(2.0) * s2;
+  T rho, u[3] = {T(0), T(0), T(0)};
+  if (velocity) {
+    T un = T(0);
+    static_for<L::D>([&](auto ac) {
+      constexpr int a = decltype(ac)::value + (3 - L::D);
+      u[a] = val[a];
+      const T t = T(nrm[a]) * u[a];
+      if constexpr (decltype(ac)::value == 0)
+        un = t;
+      else
+        un = un + t;
+    });
+    rho = fsum / (T(1.0) + un);
+  } else {
+    rho = val[0];
+    const T un = T(-1.0) + fsum / rho;
+    static_for<L::D>([&](auto ac) {
+      constexpr int a = decltype(ac)::value + (3 - L::D);
+      u[a] = un * T(nrm[a]);
+    });
+  }
+  T feq[Q];
+  equilibrium<L, T>(rho, u, feq);
+  T g[Q];
+  static_for<Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int o = opp<L>(l);
+    const T fknown = (f[o] + feq[l]) - feq[o];
+    g[l] = ((m >> l) & 1u) ? fknown : f[l];
+  });
+  if (regularized) {
+    T fneq[Q];
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      fneq[l] = g[l] - feq[l];
+    });
+    T pi[6];
+    second_moment<L, T>(fneq, pi);
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      T qp = T(0);
+      static_for<n_pi<L>()>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T t = T(qi<L>(l, k)) * pi[k];
+        if constexpr (k == 0)
+          qp = t;
+        else
+          qp = qp + t;
+      });
+      g[l] = feq[l] + (T(9.0 / 2.0) * T(L::w(l))) * qp;
+    });
+  }
+  static_for<Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    f[l] = g[l];
+  });
+}
+
 template <class L, class T, int COLL>
 __device__ __forceinline__ void collide(T (&f)[L::Q], T omega) {
   T rho, u[3];

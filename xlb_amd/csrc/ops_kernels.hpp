@@ -169,7 +169,24 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
   if (b != id) return;
   const size_t ip = cell_index(f_pre, d, x, y, z), io = cell_index(f_post, d, x, y, z);
   unsigned m = 0;
-  if (kind == XLBHIP_BC_HALFWAY_BB) m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+  if (kind == XLBHIP_BC_HALFWAY_BB || kind >= XLBHIP_BC_ZOUHE_VELOCITY) m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+  if (kind >= XLBHIP_BC_ZOUHE_VELOCITY) {
+    T ff[L::Q], val[3];
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      ff[l] = load_rt<T>(f_post, (size_t)l * f_post.plane_stride + io);
+    });
+    val[0] = static_cast<T>(vals.v[0]);
+    val[1] = static_cast<T>(vals.v[1]);
+    val[2] = static_cast<T>(vals.v[2]);
+    zouhe_cell<L, T>(ff, m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
+                     kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, ff[l]);
+    });
+    return;
+  }
   static_for<L::Q>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     constexpr int o = opp<L>(l);

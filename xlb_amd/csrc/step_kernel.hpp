@@ -133,9 +133,11 @@ __device__ __forceinline__ unsigned kind_of(const StepArgs<T, S>& a, unsigned id
   return kind;
 }
 
+// HASBC: 0 = no boundary conditions, 1 = the basic kinds (equilibrium, bounce-back, do-nothing),
+// 2 = basic + Zou-He / Regularized (kept out of the basic variant to protect its register budget).
 // FLAGS bit 0: non-temporal stores; bit 1: non-temporal loads of the c_z == 0 directions;
 // bit 2: non-temporal loads of the z-shifted directions too (VEC == 1)
-template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
+template <class L, class T, class S, int VEC, int COLL, int HASBC, int FLAGS>
 __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArgs<T, S> a) {
   constexpr int Q = L::Q;
   constexpr unsigned ES = sizeof(S);
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
   const unsigned cell_in_plane = (unsigned)y * (unsigned)nz + (unsigned)z0;  // elements, < 2^30
   unsigned ids[VEC];
   bool any_bc = false;
-  if constexpr (HASBC) {
+  if constexpr (HASBC != 0) {
     const uint8_t* bcp = a.bc + (size_t)Xs[1] * plane_cells;  // uniform
     if constexpr (VEC == 4) {
       const unsigned wrd = ld(reinterpret_cast<const unsigned*>(bcp), cell_in_plane);
@@ -245,7 +247,7 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
 #pragma unroll
   for (int k = 0; k < VEC; ++k) {
     bool fullway = false;
-    if constexpr (HASBC) {
+    if constexpr (HASBC != 0) {
       if (any_bc && ids[k] != 0u) {
         const unsigned id = ids[k];
         const unsigned kind = kind_of(a, id);
@@ -288,6 +290,14 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
           });
         } else if (kind == K_FW) {
           fullway = true;
+        } else if constexpr (HASBC == 2) {
+          // extended kernel variant only: Zou-He / Regularized inlets and outlets (bc_zouhe.py, bc_regularized.py)
+          if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
+            const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
+            const T* val = opaque(a.bc_values + id * 27u);
+            zouhe_cell<L, T>(f[k], m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
+                             kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
+          }
         }
       }
     }

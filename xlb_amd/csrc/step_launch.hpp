@@ -22,7 +22,7 @@ struct StepLaunch {
   double omega;
   int compute_dtype, store_dtype;
   int vec;     // requested cells per thread (1, 2, 4); must divide nz
-  int has_bc;  // 0: bc_mask known to be all zero
+  int has_bc;  // 0: no BCs; 1: basic kinds; 2: + Zou-He / Regularized
   int flags;   // bit 0: non-temporal stores
   int block_threads;  // 0 = default (256)
   int block_tz;       // threads along z per block, 0 = as many as fit
@@ -44,7 +44,7 @@ inline int pick_vec(int compute_dtype, int nz, int requested, int collision) {
   return v;
 }
 
-template <class L, class T, class S, int VEC, int COLL, bool HASBC, int FLAGS>
+template <class L, class T, class S, int VEC, int COLL, int HASBC, int FLAGS>
 int launch_typed(const StepLaunch& p) {
   StepArgs<T, S> a;
   a.src = static_cast<const S*>(p.src);
@@ -87,7 +87,7 @@ int launch_typed(const StepLaunch& p) {
   return 0;
 }
 
-template <class L, class T, class S, int VEC, int COLL, bool HASBC>
+template <class L, class T, class S, int VEC, int COLL, int HASBC>
 int launch_flags(const StepLaunch& p) {
 #ifdef XLB_TUNE_VARIANTS
   switch (p.flags & 7) {
@@ -104,8 +104,9 @@ int launch_flags(const StepLaunch& p) {
 
 template <class L, class T, class S, int VEC, int COLL>
 int launch_vec(const StepLaunch& p) {
-  if (p.has_bc) return launch_flags<L, T, S, VEC, COLL, true>(p);
-  return launch_flags<L, T, S, VEC, COLL, false>(p);
+  if (p.has_bc == 2) return launch_flags<L, T, S, VEC, COLL, 2>(p);
+  if (p.has_bc == 1) return launch_flags<L, T, S, VEC, COLL, 1>(p);
+  return launch_flags<L, T, S, VEC, COLL, 0>(p);
 }
 
 template <class L, class T, class S, int COLL>

@@ -6,4 +6,6 @@ from .boundary_condition import (
     HalfwayBounceBackBC as HalfwayBounceBackBC,
     FullwayBounceBackBC as FullwayBounceBackBC,
     DoNothingBC as DoNothingBC,
+    ZouHeBC as ZouHeBC,
+    RegularizedBC as RegularizedBC,
 )

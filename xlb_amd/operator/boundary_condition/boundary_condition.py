@@ -1,4 +1,5 @@
-"""Boundary-condition base class, id registry and the four in-scope conditions.
+"""Boundary-condition base class, id registry, the four in-scope conditions and the Zou-He /
+Regularized inlet-outlet pair.
 
 Reference: xlb/operator/boundary_condition/boundary_condition.py:26-136 (base, flags,
 ``pad_indices``), boundary_condition_registry.py:6-30 (process-global id counter starting at 1,
@@ -199,6 +200,68 @@ class DoNothingBC(BoundaryCondition):
                  voxelization_method=None):
         super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
                          voxelization_method)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class ZouHeBC(BoundaryCondition):
+    """Zou-He inlet / outlet: non-equilibrium bounce-back of the missing populations around
+    feq(rho, u) with either the normal velocity or the density prescribed
+    (reference xlb/operator/boundary_condition/bc_zouhe.py:37-304, JAX semantics: a CONSTANT
+    ``prescribed_value`` lives in the BC object; callable profiles are out of scope here)."""
+
+    _kinds = {"velocity": _lib.BC_ZOUHE_VELOCITY, "pressure": _lib.BC_ZOUHE_PRESSURE}
+
+    def __init__(self, bc_type, profile=None, prescribed_value=None, velocity_set=None, precision_policy=None, compute_backend=None,
+                 indices=None, mesh_vertices=None, voxelization_method=None):
+        assert bc_type in ["velocity", "pressure"], f"type = {bc_type} not supported! Use 'pressure' or 'velocity'."
+        self.bc_type = bc_type
+        super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+        self.hip_kind = self._kinds[bc_type]
+        if profile is not None:
+            if prescribed_value is not None:
+                raise ValueError("Cannot specify both profile and prescribed_value")
+            raise NotImplementedError("callable profiles are out of scope of the HIP backend; use prescribed_value")
+        if prescribed_value is None:
+            raise ValueError("prescribed_value is required")
+        if bc_type == "velocity":
+            if not isinstance(prescribed_value, (tuple, list, np.ndarray)):
+                raise ValueError("Velocity prescribed_value must be a tuple, list, or array-like")
+            prescribed_value = np.asarray(prescribed_value, dtype=np.float64)
+            if prescribed_value.shape != (self.velocity_set.d,):
+                raise ValueError(f"prescribed_value must have {self.velocity_set.d} components")
+        else:
+            if not isinstance(prescribed_value, (int, float)):
+                raise ValueError("Pressure prescribed_value must be a scalar (int or float)")
+            prescribed_value = float(prescribed_value)
+        if np.count_nonzero(prescribed_value) > 1:
+            raise ValueError("This BC only supports normal prescribed values (only one non-zero element allowed)")
+        self.prescribed_value = prescribed_value
+        self.needs_padding = True
+
+    def _hip_values(self):
+        S = self.store_dtype
+        out = np.zeros(27)
+        if self.bc_type == "velocity":
+            v = self.prescribed_value.astype(S).astype(np.float64)  # bc_zouhe.py:155-156: store precision first
+            out[3 - self.velocity_set.d : 3] = v  # internal 3-component form
+        else:
+            out[0] = float(S(self.prescribed_value))
+        return out
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class RegularizedBC(ZouHeBC):
+    """Zou-He followed by the regularisation of the boundary populations,
+    f = feq + 9/2 w_l Q_l : Pi^neq (reference bc_regularized.py:25-137)."""
+
+    _kinds = {"velocity": _lib.BC_REGULARIZED_VELOCITY, "pressure": _lib.BC_REGULARIZED_PRESSURE}
 
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
