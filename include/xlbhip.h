@@ -49,7 +49,11 @@ enum {
 enum { XLBHIP_D2Q9 = 0, XLBHIP_D3Q19 = 1, XLBHIP_D3Q27 = 2 };
 
 /* collision models; xlb/operator/stepper/nse_stepper.py:78-84 */
-enum { XLBHIP_BGK = 0, XLBHIP_KBC = 1 };
+enum {
+  XLBHIP_BGK = 0,
+  XLBHIP_KBC = 1,
+  XLBHIP_SMAGORINSKY_LES_BGK = 2 /* xlb/operator/collision/smagorinsky_les_bgk.py:44-60 (section 8f rank 3) */
+};
 
 /* boundary-condition kinds (in scope: SURVEY.md section 8 rows a7-a9, + DoNothing) */
 enum {
@@ -149,6 +153,11 @@ int xlbhip_build_masks(xlbhip_ctx* ctx, int lattice, int n_bc, const int32_t* bc
 int xlbhip_stepper_create(xlbhip_ctx* ctx, int lattice, int collision, int compute_dtype, int store_dtype, int n_bc,
                           const xlbhip_bc_desc* bcs, xlbhip_stepper** out);
 int xlbhip_stepper_destroy(xlbhip_stepper* s);
+/* ForcedCollision with the exact-difference scheme (forced_collision.py:44-50, exact_difference_force.py:61-83):
+ * force[3] in the internal 3-component form; NULL switches forcing off */
+int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force);
+/* Smagorinsky constant of XLBHIP_SMAGORINSKY_LES_BGK (default 0.17, smagorinsky_les_bgk.py:36) */
+int xlbhip_stepper_set_smagorinsky(xlbhip_stepper* s, double coef);
 /* one step: reads f_src, writes f_dst (caller swaps); omega is cast to compute dtype (bgk.py:31) */
 int xlbhip_step(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_dst, const xlbhip_field* bc_mask,
                 const xlbhip_field* missing_mask, double omega, int64_t timestep);

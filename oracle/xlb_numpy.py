@@ -293,6 +293,44 @@ def kbc(f, feq, omega, lat):
     return f - beta * (T(2.0) * delta_s + gamma[None] * delta_h)
 
 
+def smagorinsky_les_bgk(f, feq, omega, lat, smagorinsky_coef=0.17):
+    """BGK with the Smagorinsky effective relaxation time.
+    xlb/operator/collision/smagorinsky_les_bgk.py:44-60"""
+    T = f.dtype.type
+    fneq = f - feq
+    pi = second_moment(fneq, lat)
+    if lat.d == 3:
+        diag, off = (0, 3, 5), (1, 2, 4)
+    else:
+        diag, off = (0, 2), (1,)
+    sd = _seq_sum_arrays([pi[k] * pi[k] for k in diag])
+    so = _seq_sum_arrays([pi[k] * pi[k] for k in off])
+    strain = sd + T(2.0) * so
+    tau0 = T(1.0) / T(omega)
+    cs = T(smagorinsky_coef)
+    tau = T(0.5) * (tau0 + np.sqrt(tau0 * tau0 + (T(36.0) * (cs * cs)) * np.sqrt(strain)))
+    omega_eff = T(1.0) / tau
+    return f - omega_eff[None] * fneq
+
+
+def _seq_sum_arrays(terms):
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = acc + t
+    return acc
+
+
+def exact_difference_force(f_post, feq, lat, force_vector):
+    """ForcedCollision + ExactDifference: moments of the post-collision populations, then
+    f += feq(rho, u + F) - feq.  xlb/operator/collision/forced_collision.py:44-50,
+    xlb/operator/force/exact_difference_force.py:61-83"""
+    T = f_post.dtype.type
+    rho, u = macroscopic(f_post, lat)
+    du = np.asarray(force_vector, dtype=T).reshape((lat.d,) + (1,) * lat.d)
+    feq_force = equilibrium(rho, u + du, lat, T)
+    return f_post + (feq_force - feq)
+
+
 # ----------------------------------------------------------------------------
 # Boundary conditions
 # ----------------------------------------------------------------------------
@@ -457,7 +495,7 @@ def build_masks(shape, lat, bcs, missing_in=None, bc_mask_in=None):
 # ----------------------------------------------------------------------------
 # The step
 # ----------------------------------------------------------------------------
-def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collision="BGK"):
+def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collision="BGK", force_vector=None):
     """One pull-scheme LBM step -> f_1 (store dtype).
     xlb/operator/stepper/nse_stepper.py:237-282."""
     T = compute_dtype(policy)
@@ -473,19 +511,23 @@ def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collisi
         post_coll = bgk(post_stream, feq, omega)
     elif collision == "KBC":
         post_coll = kbc(post_stream, feq, omega, lat)
+    elif collision == "SmagorinskyLESBGK":
+        post_coll = smagorinsky_les_bgk(post_stream, feq, omega, lat)
     else:
         raise ValueError(collision)
+    if force_vector is not None:
+        post_coll = exact_difference_force(post_coll, feq, lat, force_vector)
     for bc in bcs:
         if bc.step == STEP_COLLISION:
             post_coll = apply_bc(bc, post_stream, post_coll, bc_mask, missing_mask, lat, policy)
     return post_coll.astype(S)
 
 
-def run(f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, policy="FP32FP32", collision="BGK"):
+def run(f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, policy="FP32FP32", collision="BGK", force_vector=None):
     """The caller's loop: step then swap (examples/cfd/lid_driven_cavity_2d.py:64-67)."""
     f = f_0
     for _ in range(n_steps):
-        f = step(f, bc_mask, missing_mask, bcs, omega, lat, policy, collision)
+        f = step(f, bc_mask, missing_mask, bcs, omega, lat, policy, collision, force_vector)
     return f
 
 

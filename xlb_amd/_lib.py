@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("XLBHIP_LIB") or os.path.join(_HERE, "lib", "libxlbhip
 # element types (include/xlbhip.h)
 F64, F32, F16, U8, BOOL, MISSING = 0, 1, 2, 3, 4, 5
 D2Q9, D3Q19, D3Q27 = 0, 1, 2
-BGK, KBC = 0, 1
+BGK, KBC, SMAGORINSKY_LES_BGK = 0, 1, 2
 BC_EQUILIBRIUM, BC_HALFWAY_BB, BC_FULLWAY_BB, BC_DO_NOTHING = 1, 2, 3, 4
 BC_ZOUHE_VELOCITY, BC_ZOUHE_PRESSURE, BC_REGULARIZED_VELOCITY, BC_REGULARIZED_PRESSURE = 5, 6, 7, 8
 UNIQUE_ID_BYTES = 128
@@ -68,6 +68,8 @@ SIGNATURES = {
     "xlbhip_build_masks": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "xlbhip_stepper_create": [_p, _i, _i, _i, _i, _i, C.POINTER(BcDesc), _pp],
     "xlbhip_stepper_destroy": [_p],
+    "xlbhip_stepper_set_force": [_p, _p],
+    "xlbhip_stepper_set_smagorinsky": [_p, _d],
     "xlbhip_step": [_p, _p, _p, _p, _p, _d, _i64],
     "xlbhip_run": [_p, _p, _p, _p, _p, _d, _i64, _i64],
     "xlbhip_run_timed": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_float)],
@@ -296,6 +298,16 @@ class Stepper:
         arr = (BcDesc * max(n, 1))(*bc_descs)
         self._h = _p()
         check(load().xlbhip_stepper_create(ctx.handle, lattice_id, collision_id, compute_code, store_code, n, arr, C.byref(self._h)))
+
+    def set_force(self, force3):
+        if force3 is None:
+            check(load().xlbhip_stepper_set_force(self._h, None))
+        else:
+            arr = (C.c_double * 3)(*[float(x) for x in force3])
+            check(load().xlbhip_stepper_set_force(self._h, C.cast(arr, C.c_void_p)))
+
+    def set_smagorinsky(self, coef):
+        check(load().xlbhip_stepper_set_smagorinsky(self._h, float(coef)))
 
     def step(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
         check(load().xlbhip_step(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))

@@ -73,13 +73,17 @@ using namespace xlb;
 template <class L, class T>
 static int collide_launch(xlbhip_ctx* c, int coll, const xlbhip_field* f, const xlbhip_field* feq, xlbhip_field* fo, double omega) {
   const size_t n = f->cells();
+  const T cs = (T)((double)opt(c, "smagorinsky_coef_e6", 170000) * 1e-6);
   if (coll == XLBHIP_BGK) {
-    hipLaunchKernelGGL((k_collide<L, T, XLBHIP_BGK>), blocks_for(n), 256, 0, c->stream, view(f), view(feq), view(fo), dims(f), (T)omega);
+    hipLaunchKernelGGL((k_collide<L, T, XLBHIP_BGK>), blocks_for(n), 256, 0, c->stream, view(f), view(feq), view(fo), dims(f), (T)omega, cs);
+  } else if (coll == XLBHIP_SMAGORINSKY_LES_BGK) {
+    hipLaunchKernelGGL((k_collide<L, T, XLBHIP_SMAGORINSKY_LES_BGK>), blocks_for(n), 256, 0, c->stream, view(f), view(feq), view(fo), dims(f),
+                       (T)omega, cs);
   } else {
     if constexpr (L::ID == XLBHIP_D3Q19) {
       XLB_FAIL("Velocity set not supported: D3Q19 has no KBC (reference kbc.py:65-66)");
     } else {
-      hipLaunchKernelGGL((k_collide<L, T, XLBHIP_KBC>), blocks_for(n), 256, 0, c->stream, view(f), view(feq), view(fo), dims(f), (T)omega);
+      hipLaunchKernelGGL((k_collide<L, T, XLBHIP_KBC>), blocks_for(n), 256, 0, c->stream, view(f), view(feq), view(fo), dims(f), (T)omega, cs);
     }
   }
   XLB_HIP(hipGetLastError());
@@ -117,6 +121,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["xcd_swizzle"] = 0;      // blocks of one row on one XCD (see step_kernel.hpp)
   c->opts["block_tz"] = 0;         // threads along z per block (0 = a whole row when it fits)
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
+  c->opts["smagorinsky_coef_e6"] = 170000;  // Smagorinsky constant x 1e6 for the STAND-ALONE collision operator (0.17)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
   return 0;
@@ -448,7 +453,7 @@ int xlbhip_collide(xlbhip_ctx* c, int lattice, int coll, int cdt, const xlbhip_f
   XLB_CHECK_POP(feq, lattice, "collide(feq)");
   XLB_CHECK_POP(fo, lattice, "collide(fout)");
   XLB_REQUIRE(same_grid(f, feq) && same_grid(f, fo), "collide: grids differ");
-  XLB_REQUIRE(coll == XLBHIP_BGK || coll == XLBHIP_KBC, "unknown collision %d", coll);
+  XLB_REQUIRE(coll == XLBHIP_BGK || coll == XLBHIP_KBC || coll == XLBHIP_SMAGORINSKY_LES_BGK, "unknown collision %d", coll);
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
   return by_lattice(lattice, [&](auto L) {
     using LL = decltype(L);
@@ -560,6 +565,9 @@ struct xlbhip_stepper {
   int n_bc = 0;
   bool needs_missing = false;
   bool extended_bcs = false;
+  bool forced = false;
+  double force[3] = {0, 0, 0};
+  double smag_cs = 0.17;
   uint8_t* tab_kind = nullptr;  // device [256]
   unsigned long long ids_packed = 0;
   unsigned kinds_packed = 0;
@@ -569,6 +577,12 @@ struct xlbhip_stepper {
 namespace xlb {
 
 static int launch_any(const xlbhip_stepper* s, const StepLaunch& p) {
+  if (s->forced || s->collision == XLBHIP_SMAGORINSKY_LES_BGK) {
+    const int coll = s->collision | (s->forced ? COLL_FORCED : 0);
+    if (s->lattice == XLBHIP_D2Q9) return launch_step_d2q9_ext(p, coll);
+    if (s->lattice == XLBHIP_D3Q19) return launch_step_d3q19_ext(p, coll);
+    return launch_step_d3q27_ext(p, coll);
+  }
   if (s->lattice == XLBHIP_D2Q9) return s->collision == XLBHIP_BGK ? launch_step_d2q9_bgk(p) : launch_step_d2q9_kbc(p);
   if (s->lattice == XLBHIP_D3Q19) return launch_step_d3q19_bgk(p);
   return s->collision == XLBHIP_BGK ? launch_step_d3q27_bgk(p) : launch_step_d3q27_kbc(p);
@@ -615,6 +629,10 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.nz = src->nz;
   p.halo = src->halo;
   p.omega = omega;
+  p.force[0] = s->force[0];
+  p.force[1] = s->force[1];
+  p.force[2] = s->force[2];
+  p.smag_cs = s->smag_cs;
   p.compute_dtype = s->cdt;
   p.store_dtype = s->sdt;
   p.vec = (int)opt(c, "vec", 0);
@@ -666,7 +684,7 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
                           xlbhip_stepper** out) {
   XLB_REQUIRE(c && out, "null argument");
   XLB_REQUIRE(lattice_q(lattice) > 0, "unknown lattice %d", lattice);
-  XLB_REQUIRE(collision == XLBHIP_BGK || collision == XLBHIP_KBC, "unknown collision %d", collision);
+  XLB_REQUIRE(collision == XLBHIP_BGK || collision == XLBHIP_KBC || collision == XLBHIP_SMAGORINSKY_LES_BGK, "unknown collision %d", collision);
   XLB_REQUIRE(!(collision == XLBHIP_KBC && lattice == XLBHIP_D3Q19), "Velocity set not supported: D3Q19 has no KBC (reference kbc.py:65-66)");
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
   XLB_REQUIRE(is_float(sdt) && dtype_size(sdt) <= dtype_size(cdt), "bad store dtype %d for compute dtype %d", sdt, cdt);
@@ -714,6 +732,19 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
     XLB_HIP(hipMemcpy(s->tab_values, vals.data(), vals.size() * 8, hipMemcpyHostToDevice));
   }
   *out = s;
+  return 0;
+}
+
+int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force) {
+  XLB_REQUIRE(s, "stepper is null");
+  s->forced = force != nullptr;
+  for (int a = 0; a < 3; ++a) s->force[a] = force ? force[a] : 0.0;
+  return 0;
+}
+
+int xlbhip_stepper_set_smagorinsky(xlbhip_stepper* s, double coef) {
+  XLB_REQUIRE(s, "stepper is null");
+  s->smag_cs = coef;
   return 0;
 }
 

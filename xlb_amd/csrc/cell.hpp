@@ -378,18 +378,57 @@ __device__ __forceinline__ void zouhe_cell(T (&f)[L::Q], unsigned m, const T* va
   });
 }
 
+// Smagorinsky LES BGK (smagorinsky_les_bgk.py:44-60)
+template <class L, class T>
+__device__ __forceinline__ void smagorinsky(T (&f)[L::Q], const T (&feq)[L::Q], T omega, T cs) {
+  T fneq[L::Q];
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    fneq[l] = f[l] - feq[l];
+  });
+  T pi[6];
+  second_moment<L, T>(fneq, pi);
+  T strain;
+  if constexpr (L::D == 3) {
+    const T sd = (pi[0] * pi[0] + pi[3] * pi[3]) + pi[5] * pi[5];
+    const T so = (pi[1] * pi[1] + pi[2] * pi[2]) + pi[4] * pi[4];
+    strain = sd + T(2.0) * so;
+  } else {
+    const T sd = pi[0] * pi[0] + pi[2] * pi[2];
+    const T so = pi[1] * pi[1];
+    strain = sd + T(2.0) * so;
+  }
+  const T tau0 = T(1.0) / omega;
+  const T tau = T(0.5) * (tau0 + sqrt(tau0 * tau0 + (T(36.0) * (cs * cs)) * sqrt(strain)));
+  const T omega_eff = T(1.0) / tau;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    f[l] = f[l] - omega_eff * fneq[l];
+  });
+}
+
+// COLL: bits 0-1 = XLBHIP_BGK / XLBHIP_KBC / XLBHIP_SMAGORINSKY_LES_BGK, bit 2 = exact-difference forcing
+constexpr int COLL_FORCED = 4;
+
+struct CollideExtra {
+  double force[3];
+  double smag_cs;
+};
+
 template <class L, class T, int COLL>
-__device__ __forceinline__ void collide(T (&f)[L::Q], T omega) {
+__device__ __forceinline__ void collide(T (&f)[L::Q], T omega, const CollideExtra& ex) {
+  constexpr int BASE = COLL & 3;
+  constexpr bool FORCED = (COLL & COLL_FORCED) != 0;
   T rho, u[3];
   moments<L, T>(f, rho, u);
-  if constexpr (COLL == XLBHIP_BGK) {
+  if constexpr (!FORCED && BASE == XLBHIP_BGK) {
     const T usqr = usqr_of<L, T>(u);
     static_for<L::Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       const T fneq = f[l] - feq_dir<L, T, l>(rho, u, usqr);
       f[l] = f[l] - omega * fneq;
     });
-  } else if constexpr (sizeof(T) == 8) {
+  } else if constexpr (!FORCED && BASE == XLBHIP_KBC && sizeof(T) == 8) {
     // fp64: 4 x q live doubles do not fit the register file at a useful occupancy; re-evaluating feq
     // wins (D3Q27 FP64FP32 384^3: 16 975 vs 15 089 MLUPS).  In fp32 the array form is faster
     // (22 380 vs 17 898 MLUPS): the kernel is VALU-bound there, not occupancy-bound.
@@ -397,7 +436,26 @@ __device__ __forceinline__ void collide(T (&f)[L::Q], T omega) {
   } else {
     T feq[L::Q];
     equilibrium<L, T>(rho, u, feq);
-    kbc<L, T>(f, feq, omega);
+    if constexpr (BASE == XLBHIP_BGK)
+      bgk<L, T>(f, feq, omega);
+    else if constexpr (BASE == XLBHIP_KBC)
+      kbc<L, T>(f, feq, omega);
+    else
+      smagorinsky<L, T>(f, feq, omega, T(ex.smag_cs));
+    if constexpr (FORCED) {
+      // forced_collision.py:47-49 + exact_difference_force.py:80-82
+      T rho2, u2[3];
+      moments<L, T>(f, rho2, u2);
+      static_for<3>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        if constexpr (a >= 3 - L::D) u2[a] = u2[a] + T(ex.force[a]);
+      });
+      const T usqr2 = usqr_of<L, T>(u2);
+      static_for<L::Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        f[l] = f[l] + (feq_dir<L, T, l>(rho2, u2, usqr2) - feq[l]);
+      });
+    }
   }
 }
 

@@ -132,7 +132,7 @@ __global__ void k_second_moment(FieldView f, FieldView pi, Dims d) {
 
 // BGK()/KBC()(f, feq, fout, omega): bgk.py:27-32, kbc.py:40-79
 template <class L, class T, int COLL>
-__global__ void k_collide(FieldView f, FieldView feq, FieldView fout, Dims d, T omega) {
+__global__ void k_collide(FieldView f, FieldView feq, FieldView fout, Dims d, T omega, T smag_cs) {
   int x, y, z;
   if (!cell_of_thread(d, x, y, z)) return;
   T ff[L::Q], fe[L::Q];
@@ -144,8 +144,10 @@ __global__ void k_collide(FieldView f, FieldView feq, FieldView fout, Dims d, T 
   });
   if constexpr (COLL == XLBHIP_BGK)
     bgk<L, T>(ff, fe, omega);
-  else
+  else if constexpr (COLL == XLBHIP_KBC)
     kbc<L, T>(ff, fe, omega);
+  else
+    smagorinsky<L, T>(ff, fe, omega, smag_cs);
   const size_t o = cell_index(fout, d, x, y, z);
   static_for<L::Q>([&](auto lc) {
     constexpr int l = decltype(lc)::value;

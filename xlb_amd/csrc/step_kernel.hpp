@@ -47,6 +47,7 @@ struct StepArgs {
   int halo;             // ghost planes per side (0: periodic wrap in x done here)
   int x_begin;          // first interior x plane updated by this launch
   int nzq;              // nz / VEC
+  CollideExtra extra;   // force vector / Smagorinsky constant (only read by the variants that use them)
   int xcd_swizzle;      // remap blockIdx so that the blocks of one row share an XCD (needs gridDim.y % 8 == 0)
   T omega;
 };
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
       }
     }
     if (!fullway) {
-      collide<L, T, COLL>(f[k], a.omega);
+      collide<L, T, COLL>(f[k], a.omega, a.extra);
     } else {
       // bc_fullway_bounce_back.py:52-56: f_post_collision[l] = f_post_stream[opp l]
       static_for<Q>([&](auto lc) {

@@ -20,6 +20,8 @@ struct StepLaunch {
   int nx, ny, nz, halo;
   int x_begin, x_count;
   double omega;
+  double force[3];
+  double smag_cs;
   int compute_dtype, store_dtype;
   int vec;     // requested cells per thread (1, 2, 4); must divide nz
   int has_bc;  // 0: no BCs; 1: basic kinds; 2: + Zou-He / Regularized
@@ -64,6 +66,10 @@ int launch_typed(const StepLaunch& p) {
   a.x_begin = p.x_begin;
   a.nzq = p.nz / VEC;
   a.omega = static_cast<T>(p.omega);
+  a.extra.force[0] = p.force[0];
+  a.extra.force[1] = p.force[1];
+  a.extra.force[2] = p.force[2];
+  a.extra.smag_cs = p.smag_cs;
   const int threads = p.block_threads > 0 ? p.block_threads : 256;
   // threads along z: split a row into equal chunks of whole waves (nz = 384 -> 2 x 192, not 256 + 128)
   int tz = a.nzq;
@@ -111,7 +117,7 @@ int launch_vec(const StepLaunch& p) {
 
 template <class L, class T, class S, int COLL>
 int launch_policy(const StepLaunch& p) {
-  const int v = pick_vec(p.compute_dtype, p.nz, p.vec, COLL);
+  const int v = pick_vec(p.compute_dtype, p.nz, p.vec, COLL & 3);
   if constexpr (sizeof(T) == 4) {
     if (v == 4) return launch_vec<L, T, S, 4, COLL>(p);
   }
@@ -130,7 +136,20 @@ int launch_step(const StepLaunch& p) {
   XLB_FAIL("unsupported precision policy compute=%d store=%d", c, s);
 }
 
+// Extended collisions (Smagorinsky LES, exact-difference forcing): three policies only, to bound build time
+template <class L, int COLL>
+int launch_step_ext(const StepLaunch& p) {
+  const int c = p.compute_dtype, s = p.store_dtype;
+  if (c == XLBHIP_F32 && s == XLBHIP_F32) return launch_policy<L, float, float, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F64) return launch_policy<L, double, double, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F32) return launch_policy<L, double, float, COLL>(p);
+  XLB_FAIL("SmagorinskyLESBGK / forced collisions are built for FP32FP32, FP64FP64 and FP64FP32 only (got compute=%d store=%d)", c, s);
+}
+
 // defined one per translation unit (step_<lattice>_<collision>.hip)
+int launch_step_d2q9_ext(const StepLaunch& p, int coll);
+int launch_step_d3q19_ext(const StepLaunch& p, int coll);
+int launch_step_d3q27_ext(const StepLaunch& p, int coll);
 int launch_step_d2q9_bgk(const StepLaunch& p);
 int launch_step_d2q9_kbc(const StepLaunch& p);
 int launch_step_d3q19_bgk(const StepLaunch& p);

@@ -44,3 +44,20 @@ class KBC(Collision):
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f, feq, fout, omega):
         return self._launch(f, feq, fout, omega)
+
+
+class SmagorinskyLESBGK(Collision):
+    """BGK with the Smagorinsky sub-grid model: the relaxation time is raised by the local strain
+    rate estimated from the non-equilibrium stress (reference
+    xlb/operator/collision/smagorinsky_les_bgk.py:17-60)."""
+
+    hip_collision_id = _lib.SMAGORINSKY_LES_BGK
+
+    def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None, smagorinsky_coef: float = 0.17):
+        self.smagorinsky_coef = smagorinsky_coef
+        super().__init__(velocity_set, precision_policy, compute_backend)
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f, feq, fout, omega):
+        self._ctx.set_option("smagorinsky_coef_e6", round(self.smagorinsky_coef * 1e6))
+        return self._launch(f, feq, fout, omega)

@@ -15,6 +15,8 @@ target) / :427-476 (fused Warp kernel, the structural model).
 ``Operator.__call__``).
 """
 
+import numpy as np
+
 from ... import _lib
 from ...compute_backend import ComputeBackend
 from ...helper.check_boundary_overlaps import check_bc_overlaps
@@ -22,7 +24,7 @@ from ...helper.initializers import initialize_eq
 from ...helper.nse_fields import create_nse_fields
 from ..boundary_condition import ImplementationStep
 from ..boundary_masker import IndicesBoundaryMasker
-from ..collision import BGK, KBC
+from ..collision import BGK, KBC, SmagorinskyLESBGK
 from ..equilibrium import QuadraticEquilibrium
 from ..macroscopic import Macroscopic
 from ..operator import Operator
@@ -39,7 +41,11 @@ class IncompressibleNavierStokesStepper(Stepper):
         if streaming_scheme != "pull":
             raise AssertionError(f"Unknown or unimplemented streaming scheme for backend: {ComputeBackend.HIP}")
         if force_vector is not None:
-            raise NotImplementedError("ForcedCollision is out of scope of the HIP backend (SURVEY.md section 8f)")
+            if forcing_scheme != "exact_difference":
+                raise NotImplementedError(f"Force model {forcing_scheme} not implemented!")  # forced_collision.py:40
+            force_vector = np.asarray(force_vector, dtype=np.float64)
+        self.forcing_scheme = forcing_scheme
+        self.force_vector = force_vector
         self._native = None
         super().__init__(grid, boundary_conditions)
         vs, pp, be = self.velocity_set, self.precision_policy, self.compute_backend
@@ -47,8 +53,12 @@ class IncompressibleNavierStokesStepper(Stepper):
             self.collision = BGK(vs, pp, be)
         elif collision_type == "KBC":
             self.collision = KBC(vs, pp, be)
+        elif collision_type == "SmagorinskyLESBGK":
+            self.collision = SmagorinskyLESBGK(vs, pp, be)
         else:
-            raise NotImplementedError(f"collision_type {collision_type!r} is out of scope of the HIP backend (BGK, KBC)")
+            raise NotImplementedError(f"collision_type {collision_type!r} is not available on the HIP backend (BGK, KBC, SmagorinskyLESBGK)")
+        if force_vector is not None and force_vector.shape != (vs.d,):
+            raise AssertionError("Check the dimensions of the input force!")  # forced_collision.py:41
         self.stream = Stream(vs, pp, be)
         self.equilibrium = QuadraticEquilibrium(vs, pp, be)
         self.macroscopic = Macroscopic(vs, pp, be)
@@ -59,6 +69,12 @@ class IncompressibleNavierStokesStepper(Stepper):
             descs = [bc._hip_descriptor() for bc in self.boundary_conditions]
             self._native = _lib.Stepper(self._ctx, self.velocity_set.hip_id, self.collision.hip_collision_id, self._compute_code,
                                         self._store_code, descs)
+            if isinstance(self.collision, SmagorinskyLESBGK):
+                self._native.set_smagorinsky(self.collision.smagorinsky_coef)
+            if self.force_vector is not None:
+                f3 = np.zeros(3)
+                f3[3 - self.velocity_set.d :] = self.force_vector  # internal 3-component form
+                self._native.set_force(f3)
         return self._native
 
     def prepare_fields(self, initializer=None):
