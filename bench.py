@@ -50,11 +50,14 @@ def parse():
 
 def cavity_bcs(grid, walls_cls, EquilibriumBC):
     """The reference harness's cavity (mlups_3d.py:193-204) on the GLOBAL box."""
-    box = grid.bounding_box_indices()
-    box_ne = grid.bounding_box_indices(remove_edges=True)
+    box = grid.bounding_box_indices(as_numpy=True)
+    box_ne = grid.bounding_box_indices(remove_edges=True, as_numpy=True)
     lid = box_ne["top"]
-    walls = [np.concatenate([np.asarray(box[f][i], np.int32) for f in ("bottom", "left", "right", "front", "back")]) for i in range(3)]
-    walls = np.unique(np.stack(walls), axis=-1)
+    walls = np.concatenate([box[f] for f in ("bottom", "left", "right", "front", "back")], axis=1).astype(np.int64)
+    # the reference driver's np.unique(walls, axis=-1) (mlups_3d.py:198), done on linear keys (same set, same order)
+    nx, ny, nz = grid.shape
+    keys = np.unique((walls[0] * ny + walls[1]) * nz + walls[2])
+    walls = np.stack([keys // (ny * nz), (keys // nz) % ny, keys % nz]).astype(np.int32)
     return [EquilibriumBC(rho=1.0, u=(0.02, 0.0, 0.0), indices=lid), walls_cls(indices=walls)]
 
 

@@ -30,13 +30,14 @@ class Grid:
     def get_compute_backend(self):
         return self.compute_backend
 
-    def bounding_box_indices(self, shape=None, remove_edges=False):
+    def bounding_box_indices(self, shape=None, remove_edges=False, as_numpy=False):
         """Index lists of the faces of the box, same contents and ordering as the reference
         (grid.py:135-191): "bottom"/"top" = last axis 0 / n-1, "left"/"right" = x, and in 3-D
         "front"/"back" = y; ``remove_edges`` trims every tangential range by one cell.
 
         Built from per-face ``np.meshgrid`` ranges instead of a full ``np.indices(shape)``
-        array, so a 512^3 domain does not allocate 3.2 GB on the host."""
+        array, so a 512^3 domain does not allocate 3.2 GB on the host.  ``as_numpy=True`` (an extension)
+        returns ``(dim, n)`` int32 arrays instead of nested Python lists — what large drivers want."""
         shape = tuple(self.shape if shape is None else shape)
         dim = len(shape)
         lo = 1 if remove_edges else 0
@@ -45,6 +46,8 @@ class Grid:
         def face(axis, value):
             axes = [np.array([value]) if a == axis else rng[a] for a in range(dim)]
             mesh = np.meshgrid(*axes, indexing="ij")
+            if as_numpy:
+                return np.stack([m.reshape(-1) for m in mesh]).astype(np.int32)
             return [m.reshape(-1).tolist() for m in mesh]
 
         last = dim - 1

@@ -5,17 +5,31 @@ list overwrites an earlier one at shared cells."""
 import numpy as np
 
 
+def _n_unique_columns(idx):
+    """Number of distinct index columns; linear keys + 1-D unique instead of np.unique(axis=-1),
+    which takes ~10 s on the 9 M wall cells of a 4096 x 512 x 512 cavity."""
+    idx = np.asarray(idx, dtype=np.int64)
+    if idx.shape[-1] == 0:
+        return 0
+    lo = idx.min(axis=1)
+    span = idx.max(axis=1) - lo + 1
+    key = np.zeros(idx.shape[1], dtype=np.int64)
+    for d in range(idx.shape[0]):
+        key = key * span[d] + (idx[d] - lo[d])
+    return np.unique(key).shape[0]
+
+
 def check_bc_overlaps(bclist, dim, compute_backend):
     chunks = []
     for bc in bclist:
         if getattr(bc, "indices", None) is None:
             continue
         idx = np.asarray(bc.indices)
-        if np.unique(idx, axis=-1).shape[-1] != idx.shape[-1]:
+        if _n_unique_columns(idx[:dim]) != idx.shape[-1]:
             print(f"WARNING: there are duplicate indices in {bc.__class__.__name__} and hence the order in bc list matters!")
         chunks.append(idx[:dim])
     if not chunks:
         return
     allidx = np.concatenate(chunks, axis=-1)
-    if np.unique(allidx, axis=-1).shape[-1] != allidx.shape[-1]:
+    if _n_unique_columns(allidx) != allidx.shape[-1]:
         print("WARNING: there are duplicate indices in the boundary condition list and hence the order in this list matters!")
