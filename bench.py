@@ -194,7 +194,10 @@ def main():
     achieved = b_alg * float(n) ** 3 / (step_ms * 1e-3) / 1e9  # per GPU, GB/s
     if rank != 0:
         return
-    kernel = f"k_step<{args.lattice}, {args.collision}, {args.policy}, vec{ctx.get_option('vec') or 'max'}>"
+    fused2 = (args.workload == "periodic" and ctx.get_option("fuse2") >= 1 and args.lattice == "D3Q19" and args.collision == "BGK"
+              and args.policy == "FP32FP32" and world == 1 and n % 64 == 0 and (n // 8) * (n // 64) >= 218)
+    kernel = (f"k_step2<{args.lattice}, {args.collision}, {args.policy}> (two steps per launch through LDS)" if fused2 else
+              f"k_step<{args.lattice}, {args.collision}, {args.policy}, vec{ctx.get_option('vec') or 1}>")
     out = {
         "metric": f"MLUPS (million lattice updates/s) {args.lattice} {args.collision}, {n}^3 per GPU",
         "value": round(mlups, 1),

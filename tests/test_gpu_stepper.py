@@ -235,3 +235,37 @@ def test_stepper_argument_errors():
         IncompressibleNavierStokesStepper(grid=grid, streaming_scheme="push")
     with pytest.raises(NotImplementedError):
         IncompressibleNavierStokesStepper(grid=grid, collision_type="KBC")  # D3Q19 has no KBC (kbc.py:65-66)
+
+
+@pytest.mark.parametrize("shape", [(5, 8, 64), (3, 16, 128), (1, 8, 64), (2, 24, 64)])
+@pytest.mark.parametrize("walls_cls", [None, FullwayBounceBackBC, HalfwayBounceBackBC])
+@pytest.mark.parametrize("steps", [2, 4, 7, 9])
+def test_two_step_fusion_matches_oracle(shape, walls_cls, steps):
+    """xlbhip_run with fuse2=1 (two steps per pass through LDS, step2_kernel.hpp) gives the same bits as the
+    oracle — and therefore as the single-step kernel — for every parity of the step count."""
+    ctx_opts = {"fuse2": 2}  # 2 = also the boundary-condition variant (1, the default, fuses only BC-free steppers)
+    if walls_cls is None:
+        vs, pp = init_hip("D3Q19")
+        lat = orc.Lattice("D3Q19")
+        grid = grid_factory(shape)
+        bcs, obcs = [], []
+    else:
+        grid, bcs, lat, obcs = hip_cavity_3d(shape, walls_cls)
+    ctx = get_context()
+    try:
+        for k, v in ctx_opts.items():
+            ctx.set_option(k, v)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        f_np = orc.perturbed_init(shape, lat, seed=23)
+        f_0.assign(f_np)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.6, steps)
+        if obcs:
+            o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        else:
+            o_bm, o_mm = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+        exp = orc.run(f_np, o_bm, o_mm, obcs, 1.6, lat, steps)
+        out = f_0.numpy()
+        assert np.array_equal(out, exp), f"max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out - exp).max()}"
+    finally:
+        ctx.set_option("fuse2", 1)

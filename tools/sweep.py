@@ -40,13 +40,23 @@ def main():
     vs = getattr(xlb_amd.velocity_set, args.lattice)(precision_policy=pp, compute_backend=ComputeBackend.HIP)
     xlb_amd.init(velocity_set=vs, default_backend=ComputeBackend.HIP, default_precision_policy=pp)
     ctx = get_context()
-    defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap", "xcd_swizzle", "nt_load")}
+    defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap", "xcd_swizzle", "nt_load", "fuse2", "fuse2_xcd", "fuse2_tile")}
     n = args.size
 
     def setup():
         grid = grid_factory((n, n, n))
         if args.workload == "periodic":
             bcs = []
+        elif args.workload == "one_cell":
+            # a single fullway cell: isolates the cost of the HASBC kernel variant itself
+            bcs = [FullwayBounceBackBC(indices=[[n // 2], [n // 2], [n // 2]])]
+        elif args.workload == "xwalls":
+            # walls on the two x faces only: whole planes of boundary cells, no boundary lanes elsewhere
+            b = grid.bounding_box_indices(as_numpy=True)
+            bcs = [HalfwayBounceBackBC(indices=np.concatenate([b["left"], b["right"]], axis=1))]
+        elif args.workload == "zwalls":
+            b = grid.bounding_box_indices(as_numpy=True)
+            bcs = [HalfwayBounceBackBC(indices=np.concatenate([b["bottom"], b["top"]], axis=1))]
         else:
             bcs = cavity_bcs(grid, HalfwayBounceBackBC if args.workload == "cavity_halfway" else FullwayBounceBackBC, EquilibriumBC)
         st = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type=args.collision)

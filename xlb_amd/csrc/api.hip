@@ -122,6 +122,9 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["block_tz"] = 0;         // threads along z per block (0 = a whole row when it fits)
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
   c->opts["smagorinsky_coef_e6"] = 170000;  // Smagorinsky constant x 1e6 for the STAND-ALONE collision operator (0.17)
+  c->opts["fuse2"] = 1;            // xlbhip_run: two steps per pass (step2_kernel.hpp): 0 never, 1 steppers without BCs, 2 also with BCs
+  c->opts["fuse2_tile"] = 0;       // z extent of the two-step tile: 0/64 -> 8x64, 32 -> 8x32 (two blocks per CU), 16 -> 16x16
+  c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
   return 0;
@@ -565,6 +568,8 @@ struct xlbhip_stepper {
   int n_bc = 0;
   bool needs_missing = false;
   bool extended_bcs = false;
+  uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
+  size_t meta_cells = 0;
   bool forced = false;
   double force[3] = {0, 0, 0};
   double smag_cs = 0.17;
@@ -609,15 +614,15 @@ static int check_step_fields(const xlbhip_stepper* s, const xlbhip_field* a, con
   return 0;
 }
 
-// one step src -> dst, with the slab halo protocol when the fields carry ghost planes
-static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
-                     double omega) {
+static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+                              double omega) {
   xlbhip_ctx* c = s->ctx;
   StepLaunch p;
   p.src = src->data;
   p.dst = dst->data;
   p.bc = (s->n_bc > 0 && bcm) ? static_cast<const uint8_t*>(bcm->data) : nullptr;
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
+  p.meta = nullptr;
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -642,6 +647,45 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   p.block_tz = (int)opt(c, "block_tz", 0);
   p.xcd_swizzle = (int)opt(c, "xcd_swizzle", 0);
   p.stream = c->stream;
+  p.x_begin = 0;
+  p.x_count = src->nx;
+  return p;
+}
+
+// two steps in one pass (a -> scratch-free: src -> dst holds f(t+2)); caller checked eligibility
+static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+                      double omega) {
+  StepLaunch p = make_launch(s, src, dst, bcm, miss, omega);
+  p.meta = s->meta;
+  p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
+  p.block_tz = (int)opt(s->ctx, "fuse2_tile", 0);
+  return launch_step2_d3q19_bgk(p);
+}
+
+static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
+  const int64_t mode = opt(s->ctx, "fuse2", 1);
+  if (mode == 0 || s->forced) return false;
+  StepLaunch p = make_launch(s, src, dst, bcm, miss, 1.0);
+  // mode 1 (default): only steppers without boundary conditions — there the two-step kernel is 1.35x faster;
+  // its boundary-condition variant is correct but currently slower than two single steps, so it
+  // has to be asked for explicitly (mode 2)
+  if (mode == 1 && p.has_bc != 0) return false;
+  if (!step2_eligible(p, s->lattice, s->collision)) return false;
+  if (mode == 1) {
+    // one block per CU marches a whole (8 x 64) tile column: the grid must fill the chip in whole rounds
+    // (256^3 = 128 tiles would leave half of the 256 CUs idle; measured slower than the single-step kernel)
+    const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
+    const long rounds = (tiles + cus - 1) / cus;
+    if (tiles * 100 < rounds * cus * 85) return false;
+  }
+  return true;
+}
+
+// one step src -> dst, with the slab halo protocol when the fields carry ghost planes
+static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+                     double omega) {
+  xlbhip_ctx* c = s->ctx;
+  StepLaunch p = make_launch(s, src, dst, bcm, miss, omega);
   if (src->halo == 0) {
     p.x_begin = 0;
     p.x_count = src->nx;
@@ -754,6 +798,7 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   (void)hipStreamSynchronize(s->ctx->stream);
   (void)hipFree(s->tab_kind);
   (void)hipFree(s->tab_values);
+  if (s->meta) (void)hipFree(s->meta);
   delete s;
   return 0;
 }
@@ -770,8 +815,43 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
   (void)t0;
   XLB_REQUIRE(n >= 0, "n_steps < 0");
   if (int rc = check_step_fields(s, a, b, bcm, miss)) return rc;
-  for (int64_t i = 0; i < n; ++i) {
-    if (int rc = step_once(s, (i & 1) ? b : a, (i & 1) ? a : b, bcm, miss, omega)) return rc;
+  // Result placement contract: f_a if n is even, else f_b.  With two-step fusion ("fuse2") a pair of
+  // steps is ONE pass a -> b; to keep the contract, pairs alternate direction (a -> b, b -> a, ...), and a
+  // trailing half pair (buffer parity) is fixed up by single steps.
+  int64_t i = 0;
+  xlbhip_field* cur = a;
+  xlbhip_field* oth = b;
+  if (n >= 2 && can_fuse2(s, a, b, bcm, miss)) {
+    if (s->n_bc > 0 && bcm) {
+      const size_t cells = bcm->cells();
+      if (s->meta_cells != cells) {
+        if (s->meta) XLB_HIP(hipFree(s->meta));
+        s->meta = nullptr;
+        XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
+        s->meta_cells = cells;
+      }
+      hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, s->ctx->stream, static_cast<const uint8_t*>(bcm->data),
+                         miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells);
+      XLB_HIP(hipGetLastError());
+    }
+    // choose the number of pairs so that the remaining single steps land the result in the right buffer:
+    // after P pairs the data sits in (P odd ? b : a); then r = n - 2P single steps flip r more times.
+    // P + r must be congruent to n (mod 2)  <=>  P even.  Use the largest even P with 2P <= n.
+    int64_t pairs = (n / 2) & ~int64_t(1);
+    if (pairs == 0 && n >= 2) pairs = 0;
+    for (int64_t k = 0; k < pairs; ++k) {
+      if (int rc = step_twice(s, cur, oth, bcm, miss, omega)) return rc;
+      xlbhip_field* tmp = cur;
+      cur = oth;
+      oth = tmp;
+    }
+    i = 2 * pairs;
+  }
+  for (; i < n; ++i) {
+    if (int rc = step_once(s, cur, oth, bcm, miss, omega)) return rc;
+    xlbhip_field* tmp = cur;
+    cur = oth;
+    oth = tmp;
   }
   return 0;
 }

@@ -268,6 +268,12 @@ __global__ void k_copy(const V* __restrict__ src, V* __restrict__ dst, size_t n)
   if (i < n) __builtin_nontemporal_store(src[i], dst + i);
 }
 
+// meta word of the two-step kernel: bc id | missing bit-set << 8 (D3Q19: 19 bits)
+__global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* meta, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) meta[i] = (uint32_t)bc[i] | ((miss ? miss[i] : 0u) << 8);
+}
+
 template <class E>
 __global__ void k_fill(E* p, size_t n, E v) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,277 @@
+// Two LBM steps per pass over memory ("temporal fusion"): f(t) -> f(t+2) with the intermediate
+// f(t+1) living only in LDS.
+//
+// A block owns a (TY x TZ) tile of the (y, z) plane and marches along x.  For every x it
+//   phase A: computes f(t+1) on plane x+1 for the tile grown by one cell in y and z
+//            ((TY+2) x (TZ+2) cells, periodic images included) by pulling from f(t) in global
+//            memory — exactly the single-step kernel's work — and writes the q populations into one
+//            of three LDS plane slots;
+//   phase B: computes f(t+2) on plane x for the tile proper by pulling from the three LDS slots
+//            (planes x-1, x, x+1) and stores it.
+// HBM traffic per two steps: ~(1 + halo overlap) reads + 1 write of every population instead of
+// 2 + 2.  Arithmetic is the same per-cell code (cell.hpp) in the same order, so the result is
+// bit-identical to two single steps (tests/test_gpu_stepper.py::test_two_step_fusion_*).
+//
+// Restrictions (the launcher falls back to the single-step kernel otherwise): D3Q19; fp32 compute and store; no ghost planes (single rank); ny % TY == 0,
+// nz % TZ == 0; BGK / basic boundary conditions.
+#pragma once
+#include "step_kernel.hpp"
+
+namespace xlb {
+
+// tile geometry of one instantiation
+template <int TY, int TZ>
+struct S2Geom {
+  static constexpr int EY = TY + 2, EZ = TZ + 2;
+  static constexpr int NE = EY * EZ;                     // cells of f(t+1) per plane slot (grown tile)
+  static constexpr int NB = TY * TZ;                     // output cells per plane
+  static constexpr int THREADS = (NE + 63) / 64 * 64;    // whole waves covering the grown tile
+  // blocks per CU allowed by LDS (3 x 19 x NE x 4 B of 160 KiB) -> waves per SIMD the register allocation must admit
+  static constexpr int BLOCKS_PER_CU = (160 * 1024) / (3 * 19 * NE * 4) > 2 ? 2 : (160 * 1024) / (3 * 19 * NE * 4);
+  static constexpr int WAVES_PER_SIMD = (BLOCKS_PER_CU * THREADS / 64 + 3) / 4;
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every
+// global load AND store in flight, which would serialise the software pipeline (prefetched pulls of the
+// next plane, asynchronous stores of the finished one) at each of the two barriers per plane.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// slot (0..7) of a bc id in the packed kernel arguments; ids beyond the first 8 make the stepper ineligible
+template <class T, class S>
+__device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id) {
+  unsigned slot = 0;
+#pragma unroll
+  for (int s = 0; s < MAX_FAST_BCS; ++s) {
+    const unsigned sid = (unsigned)(a.ids_packed >> (8 * s)) & 0xffu;
+    slot = (id == sid) ? (unsigned)s : slot;
+  }
+  return slot;
+}
+
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ>
+__global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
+  using G = S2Geom<TY, TZ>;
+  constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
+  constexpr unsigned ES = sizeof(S);
+  static_assert(sizeof(T) == 4, "k_step2 keeps f(t+1) as fp32 in LDS");
+  __shared__ T lds[3 * Q * NE];                          // [slot][l][cell]  (8x64 tile: 150 480 B -> one block per CU)
+  __shared__ unsigned ldsmeta[HASBC ? 3 * NE : 1];       // [slot][cell] id | missing << 8 of the f(t+1) cells
+  __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];     // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
+
+  // tile of this block; blocks b and b + 8 share an XCD, so give each XCD a compact patch of tiles
+  const unsigned tiles_z = (unsigned)a.nz / TZ, tiles_y = (unsigned)a.ny / TY;
+  unsigned tile = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const unsigned per_xcd = (tiles_y * tiles_z) / 8u;  // launcher guarantees divisibility
+    tile = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+  }
+  const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
+  const int t = threadIdx.x;
+  const int nx = a.nx, ny = a.ny, nz = a.nz;
+  const size_t plane_cells = (size_t)ny * nz;
+
+  if constexpr (HASBC != 0) {
+    if (t < MAX_FAST_BCS * 32) {
+      const unsigned s_ = (unsigned)t / 32u, l_ = (unsigned)t % 32u;
+      const unsigned id_ = (unsigned)(a.ids_packed >> (8 * s_)) & 0xffu;
+      bcval[t] = (l_ < 27u && id_ != 0u) ? a.bc_values[id_ * 27u + l_] : T(0);
+    }
+  }
+
+  // IMPORTANT for the software pipeline: every global load / store of the steady-state loop is issued
+  // UNCONDITIONALLY and in straight-line order by every thread.  Divergent code around VMEM makes hipcc's
+  // s_waitcnt insertion assume the smallest possible number of younger operations at the joins, i.e. it
+  // falls back to vmcnt(0), which drains the prefetched pulls and the asynchronous stores every plane.
+  // Idle lanes therefore shadow a valid cell (loads) or aim at the padding behind the plane (stores).
+
+  // ---- phase-A cell of this thread (grown tile, periodic images) ----
+  const bool act_a = t < NE;
+  const int ta = act_a ? t : NE - 1;
+  const int ja = ta / EZ, ka = ta % EZ;
+  int ya = ty0 - 1 + ja, za = tz0 - 1 + ka;
+  ya = ya < 0 ? ya + ny : (ya >= ny ? ya - ny : ya);
+  za = za < 0 ? za + nz : (za >= nz ? za - nz : za);
+  unsigned Yb[3], Zb[3];  // byte offsets of the y / z neighbours (index c + 1 -> source = coordinate - c)
+  Yb[0] = (unsigned)((ya + 1 == ny) ? 0 : ya + 1) * (unsigned)nz * ES;
+  Yb[1] = (unsigned)ya * (unsigned)nz * ES;
+  Yb[2] = (unsigned)((ya == 0) ? ny - 1 : ya - 1) * (unsigned)nz * ES;
+  Zb[0] = (unsigned)((za + 1 == nz) ? 0 : za + 1) * ES;
+  Zb[1] = (unsigned)za * ES;
+  Zb[2] = (unsigned)((za == 0) ? nz - 1 : za - 1) * ES;
+  const unsigned cell_a = (unsigned)ya * (unsigned)nz + (unsigned)za;
+
+  // ---- phase-B cell of this thread (tile proper); waves beyond the tile shadow a valid cell ----
+  const bool act_b = t < G::NB;
+  const int tb = act_b ? t : t % G::NB;
+  const int jb = tb / TZ, kb = tb % TZ;
+  const int yb = ty0 + jb, zb = tz0 + kb;
+  const unsigned cell_b = (unsigned)yb * (unsigned)nz + (unsigned)zb;
+  const int ctr_b = (jb + 1) * EZ + (kb + 1);  // my cell inside a grown-tile slot
+
+  auto wrapx = [&](int p) {
+    p %= nx;
+    return p < 0 ? p + nx : p;
+  };
+  auto meta_load = [&](int plane, unsigned cell) -> unsigned { return a.meta[(size_t)plane * plane_cells + cell]; };
+
+  auto finish = [&](T(&f)[Q], bool fullway) {
+    if (!fullway) {
+      collide<L, T, COLL>(f, a.omega, a.extra);
+    } else {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int o = opp<L>(l);
+        if constexpr (l < o) {
+          const T tmp = f[l];
+          f[l] = f[o];
+          f[o] = tmp;
+        }
+      });
+    }
+  };
+
+  // phase A, first half: issue the 19 pulls of plane x from f(t) (kept in registers across phase B).
+  // Boundary lanes redirect a pull: a halfway wall reads the own cell's OPPOSITE population for its missing
+  // directions, a do-nothing cell its own populations — same register, same number of loads, nothing
+  // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
+  auto issue_a = [&](int x, S(&raw)[Q], unsigned w) {
+    if (!act_a) return;  // only the tail of the last wave is idle
+    int Xs[3];
+    Xs[0] = (x + 1 == nx) ? 0 : x + 1;
+    Xs[1] = x;
+    Xs[2] = (x == 0) ? nx - 1 : x - 1;
+    bool wave_has_bc = false;
+    if constexpr (HASBC != 0) wave_has_bc = __builtin_amdgcn_ballot_w64((w & 0xffu) != 0u) != 0ull;  // wave-uniform
+    if (!wave_has_bc) {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+        const S* row = a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells;  // uniform
+        raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
+      });
+    } else if constexpr (HASBC != 0) {
+      const unsigned id = w & 0xffu, m = w >> 8;
+      const unsigned kind = (id != 0u) ? kind_fast(a, id) : (unsigned)K_NONE;
+      const bool hw = kind == K_HW, dn = kind == K_DN;
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+        const char* p_pull = reinterpret_cast<const char*>(a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells) +
+                             (Yb[cy + 1] + Zb[cz + 1]);
+        const char* p_opp = reinterpret_cast<const char*>(a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)x * plane_cells) + cell_a * ES;
+        const char* p_own = reinterpret_cast<const char*>(a.src + (size_t)l * a.plane_stride + (size_t)x * plane_cells) + cell_a * ES;
+        const char* p = (hw && ((m >> l) & 1u)) ? p_opp : (dn ? p_own : p_pull);
+        raw[l] = *reinterpret_cast<const S*>(p);
+        __builtin_amdgcn_sched_barrier(0);  // keep the 19 address pairs from being computed up front (register budget)
+      });
+    }
+  };
+  // boundary treatment on registers: f holds the (redirected) pulls
+  auto bc_regs = [&](T(&f)[Q], unsigned id, unsigned m, bool& fullway) {
+    const unsigned kind = kind_fast(a, id);
+    const T* val = bcval + slot_of(a, id) * 32u;
+    if (kind == K_EQ) {
+      static_for<Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
+    } else if (kind == K_HW) {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if ((m >> l) & 1u) f[l] = f[l] + val[l];  // f[l] already is f_pre[opp l]; + moving-wall term (0 for no-slip)
+      });
+    } else if (kind == K_FW) {
+      fullway = true;
+    }
+  };
+  // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
+  auto finish_a = [&](const S(&raw)[Q], unsigned w, int slot) {
+    if (!act_a) return;
+    T f[Q];
+    static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
+    bool fullway = false;
+    if constexpr (HASBC != 0) {
+      if ((w & 0xffu) != 0u) bc_regs(f, w & 0xffu, w >> 8, fullway);
+    }
+    finish(f, fullway);
+    if (act_a) {
+      T* dst = lds + slot * (Q * NE) + t;
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        dst[l * NE] = to_compute<T, S>(to_store<S, T>(f[l]));  // f(t+1) passes through the store precision
+      });
+      if constexpr (HASBC != 0) ldsmeta[slot * NE + t] = w;
+    }
+  };
+
+  // phase B: f(t+2) on plane x from the LDS slots of planes x-1, x, x+1 -> global (19 unconditional stores)
+  auto phase_b = [&](int x, int slot_m, int slot_0, int slot_p) {
+    if (!act_b) return;  // whole waves (NB % 64 == 0)
+    const T* base[3];  // index c_x + 1 -> plane x - c_x
+    base[0] = lds + slot_p * (Q * NE);
+    base[1] = lds + slot_0 * (Q * NE);
+    base[2] = lds + slot_m * (Q * NE);
+    unsigned w = 0;
+    if constexpr (HASBC != 0) w = ldsmeta[slot_0 * NE + ctr_b];
+    const unsigned id = w & 0xffu, m = w >> 8;
+    T f[Q];
+    bool wave_has_bc = false;
+    if constexpr (HASBC != 0) wave_has_bc = __builtin_amdgcn_ballot_w64(id != 0u) != 0ull;  // wave-uniform
+    if (!wave_has_bc) {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+        f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
+      });
+    } else if constexpr (HASBC != 0) {
+      const unsigned kind = (id != 0u) ? kind_fast(a, id) : (unsigned)K_NONE;
+      const bool hw = kind == K_HW, dn = kind == K_DN;
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+        int idx = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
+        if (hw && ((m >> l) & 1u)) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
+        if (dn) idx = slot_0 * (Q * NE) + l * NE + ctr_b;
+        f[l] = lds[idx];
+      });
+    }
+    bool fullway = false;
+    if constexpr (HASBC != 0) {
+      if (id != 0u) bc_regs(f, id, m, fullway);
+    }
+    finish(f, fullway);
+    if (act_b) {  // wave-uniform: NB is a whole number of waves
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        S* drow = a.dst + (size_t)l * a.plane_stride + (size_t)x * plane_cells;  // uniform
+        S v[1] = {to_store<S, T>(f[l])};
+        st_aligned<S, 1, true>(drow, cell_b * ES, v);
+      });
+    }
+  };
+
+  // Plane p lives in slot (p + 1) % 3 (p = -1 is the periodic image nx - 1).
+  S raw[Q];
+  unsigned w_raw = 0;
+  // prologue: planes -1, 0, 1 straight into the window (synchronous), then the pulls of plane 2 go in flight
+  for (int p = -1; p <= 1; ++p) {
+    if constexpr (HASBC != 0) w_raw = meta_load(wrapx(p), cell_a);
+    issue_a(wrapx(p), raw, w_raw);
+    if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
+    finish_a(raw, w_raw, (p + 1) % 3);
+  }
+  if constexpr (HASBC != 0) w_raw = meta_load(wrapx(2), cell_a);
+  issue_a(wrapx(2), raw, w_raw);
+  lds_barrier();
+  // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
+  // The last two trips prefetch planes nx + 1, nx + 2 (periodic images, discarded): 2 / nx extra work, no branch.
+  for (int x = 0; x < nx; ++x) {
+    unsigned wa = 0;
+    if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
+    phase_b(x, x % 3, (x + 1) % 3, (x + 2) % 3);
+    lds_barrier();  // every reader of the slot about to be overwritten (plane x - 1) is done
+    finish_a(raw, w_raw, x % 3);  // plane x + 2 -> slot (x + 3) % 3
+    w_raw = wa;
+    issue_a(wrapx(x + 3), raw, w_raw);
+    lds_barrier();  // plane x + 2 visible
+  }
+}
+
+}  // namespace xlb

@@ -37,6 +37,7 @@ struct StepArgs {
   S* dst;
   const uint8_t* bc;      // (nx+2h, ny, nz) or nullptr
   const uint32_t* miss;   // (nx+2h, ny, nz) bit-sets or nullptr
+  const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
   const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS
   unsigned long long ids_packed;  // up to 8 bc ids, one per byte
@@ -119,6 +120,20 @@ template <class P>
 __device__ __forceinline__ const P* opaque(const P* p) {
   asm volatile("" : "+v"(p));
   return p;
+}
+
+// scalar compare chain only (callers guarantee n_bc <= MAX_FAST_BCS): contains NO load, so it can sit in a
+// software-pipelined loop without making the compiler's vmcnt bookkeeping fall back to vmcnt(0)
+template <class T, class S>
+__device__ __forceinline__ unsigned kind_fast(const StepArgs<T, S>& a, unsigned id) {
+  unsigned kind = K_NONE;
+#pragma unroll
+  for (int s = 0; s < MAX_FAST_BCS; ++s) {
+    const unsigned sid = (unsigned)(a.ids_packed >> (8 * s)) & 0xffu;  // scalar
+    const unsigned sk = (a.kinds_packed >> (4 * s)) & 0xfu;            // scalar
+    kind = (id == sid) ? sk : kind;
+  }
+  return kind;
 }
 
 template <class T, class S>

@@ -11,6 +11,7 @@ struct StepLaunch {
   void* dst;
   const uint8_t* bc;
   const uint32_t* miss;
+  const uint32_t* meta;  // two-step kernel only
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
   unsigned long long ids_packed;
@@ -53,6 +54,7 @@ int launch_typed(const StepLaunch& p) {
   a.dst = static_cast<S*>(p.dst);
   a.bc = p.bc;
   a.miss = p.miss;
+  a.meta = nullptr;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const T*>(p.tab_values);
   a.ids_packed = p.ids_packed;
@@ -147,6 +149,9 @@ int launch_step_ext(const StepLaunch& p) {
 }
 
 // defined one per translation unit (step_<lattice>_<collision>.hip)
+// two steps per pass (step2_kernel.hpp): f(t) in src -> f(t+2) in dst
+bool step2_eligible(const StepLaunch& p, int lattice, int collision);
+int launch_step2_d3q19_bgk(const StepLaunch& p);
 int launch_step_d2q9_ext(const StepLaunch& p, int coll);
 int launch_step_d3q19_ext(const StepLaunch& p, int coll);
 int launch_step_d3q27_ext(const StepLaunch& p, int coll);
