@@ -124,6 +124,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["smagorinsky_coef_e6"] = 170000;  // Smagorinsky constant x 1e6 for the STAND-ALONE collision operator (0.17)
   c->opts["fuse2"] = 1;            // xlbhip_run: two steps per pass (step2_kernel.hpp): 0 never, 1 steppers without BCs, 2 also with BCs
   c->opts["fuse2_tile"] = 0;       // z extent of the two-step tile: 0/64 -> 8x64, 32 -> 8x32 (two blocks per CU), 16 -> 16x16
+  c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
@@ -568,6 +569,8 @@ struct xlbhip_stepper {
   int n_bc = 0;
   bool needs_missing = false;
   bool extended_bcs = false;
+  uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
+  int order_ty = 0, order_tz = 0;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
   size_t meta_cells = 0;
   bool forced = false;
@@ -623,6 +626,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.bc = (s->n_bc > 0 && bcm) ? static_cast<const uint8_t*>(bcm->data) : nullptr;
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
   p.meta = nullptr;
+  p.tile_order = nullptr;
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -657,6 +661,7 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
                       double omega) {
   StepLaunch p = make_launch(s, src, dst, bcm, miss, omega);
   p.meta = s->meta;
+  p.tile_order = (p.has_bc && opt(s->ctx, "fuse2_lpt", 1)) ? s->tile_order : nullptr;
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   p.block_tz = (int)opt(s->ctx, "fuse2_tile", 0);
   return launch_step2_d3q19_bgk(p);
@@ -799,6 +804,7 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   (void)hipFree(s->tab_kind);
   (void)hipFree(s->tab_values);
   if (s->meta) (void)hipFree(s->meta);
+  if (s->tile_order) (void)hipFree(s->tile_order);
   delete s;
   return 0;
 }
@@ -829,6 +835,29 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
         s->meta = nullptr;
         XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
         s->meta_cells = cells;
+      }
+      const int tys = bcm->ny / 8, tzs = bcm->nz / 64;
+      if (s->order_ty != tys || s->order_tz != tzs) {
+        // hull tiles first (the expensive ones when there are walls), then the interior in XCD-friendly order
+        std::vector<uint32_t> order;
+        order.reserve((size_t)tys * tzs);
+        for (int ty = 0; ty < tys; ++ty)
+          for (int tz = 0; tz < tzs; ++tz)
+            if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) order.push_back((uint32_t)(ty * tzs + tz));
+        std::vector<uint32_t> inner;
+        for (int ty = 1; ty < tys - 1; ++ty)
+          for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
+        const size_t n_in = inner.size(), per = (n_in + 7) / 8;
+        for (size_t i = 0; i < per * 8; ++i) {  // block i -> XCD i % 8 -> its contiguous chunk of the interior list
+          const size_t j = (i % 8) * per + i / 8;
+          if (j < n_in) order.push_back(inner[j]);
+        }
+        if (s->tile_order) XLB_HIP(hipFree(s->tile_order));
+        s->tile_order = nullptr;
+        XLB_HIP(hipMalloc(&s->tile_order, order.size() * sizeof(uint32_t)));
+        XLB_HIP(hipMemcpy(s->tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        s->order_ty = tys;
+        s->order_tz = tzs;
       }
       hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, s->ctx->stream, static_cast<const uint8_t*>(bcm->data),
                          miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells);

@@ -18,6 +18,7 @@ static int launch2(const StepLaunch& p) {
   a.bc = p.bc;
   a.miss = p.miss;
   a.meta = p.meta;
+  a.tile_order = (TY == 8 && TZ == 64) ? p.tile_order : nullptr;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const float*>(p.tab_values);
   a.ids_packed = p.ids_packed;

@@ -58,10 +58,14 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   __shared__ unsigned ldsmeta[HASBC ? 3 * NE : 1];       // [slot][cell] id | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];     // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
 
-  // tile of this block; blocks b and b + 8 share an XCD, so give each XCD a compact patch of tiles
+  // tile of this block: from the launch's order table when there is one (hull tiles first — with boundary
+  // conditions they are the expensive ones, and a CU that starts with one should get a cheap one next), else
+  // a compact patch of tiles per XCD (blocks b and b + 8 share an XCD)
   const unsigned tiles_z = (unsigned)a.nz / TZ, tiles_y = (unsigned)a.ny / TY;
   unsigned tile = blockIdx.x;
-  if (a.xcd_swizzle) {
+  if (a.tile_order) {
+    tile = a.tile_order[blockIdx.x];
+  } else if (a.xcd_swizzle) {
     const unsigned per_xcd = (tiles_y * tiles_z) / 8u;  // launcher guarantees divisibility
     tile = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
   }
@@ -134,45 +138,52 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   // Boundary lanes redirect a pull: a halfway wall reads the own cell's OPPOSITE population for its missing
   // directions, a do-nothing cell its own populations — same register, same number of loads, nothing
   // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
-  auto issue_a = [&](int x, S(&raw)[Q], unsigned w) {
+  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w) {
     if (!act_a) return;  // only the tail of the last wave is idle
     int Xs[3];
     Xs[0] = (x + 1 == nx) ? 0 : x + 1;
     Xs[1] = x;
     Xs[2] = (x == 0) ? nx - 1 : x - 1;
-    bool wave_has_bc = false;
-    if constexpr (HASBC != 0) wave_has_bc = __builtin_amdgcn_ballot_w64((w & 0xffu) != 0u) != 0ull;  // wave-uniform
-    if (!wave_has_bc) {
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        const S* row = a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells;  // uniform
-        raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
-      });
-    } else if constexpr (HASBC != 0) {
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+      const S* row = a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells;  // uniform
+      raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
+    });
+    if constexpr (HASBC != 0) {
+      // Redirected pulls of boundary lanes (halfway wall: own cell, OPPOSITE population, for its missing
+      // directions; do-nothing: own cell, same population) go out as inline-asm loads into fix[]: hipcc's
+      // s_waitcnt bookkeeping does not see them, so this divergent region leaves the vmcnt model of the
+      // steady-state loop exact (see the note above).  finish_a waits for them by hand.
       const unsigned id = w & 0xffu, m = w >> 8;
-      const unsigned kind = (id != 0u) ? kind_fast(a, id) : (unsigned)K_NONE;
-      const bool hw = kind == K_HW, dn = kind == K_DN;
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        const char* p_pull = reinterpret_cast<const char*>(a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells) +
-                             (Yb[cy + 1] + Zb[cz + 1]);
-        const char* p_opp = reinterpret_cast<const char*>(a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)x * plane_cells) + cell_a * ES;
-        const char* p_own = reinterpret_cast<const char*>(a.src + (size_t)l * a.plane_stride + (size_t)x * plane_cells) + cell_a * ES;
-        const char* p = (hw && ((m >> l) & 1u)) ? p_opp : (dn ? p_own : p_pull);
-        raw[l] = *reinterpret_cast<const S*>(p);
-        __builtin_amdgcn_sched_barrier(0);  // keep the 19 address pairs from being computed up front (register budget)
-      });
+      if (id != 0u) {
+        const unsigned kind = kind_fast(a, id);
+        const bool hw = kind == K_HW, dn = kind == K_DN;
+        if (hw || dn) {
+          static_for<Q>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if (dn || ((m >> l) & 1u)) {
+              const S* p = a.src + (size_t)(dn ? l : opp<L>(l)) * a.plane_stride + (size_t)x * plane_cells + cell_a;
+              S got;
+              asm volatile("global_load_dword %0, %1, off" : "=v"(got) : "v"(p) : "memory");
+              fix[l] = got;
+            }
+          });
+        }
+      }
     }
   };
   // boundary treatment on registers: f holds the (redirected) pulls
   auto bc_regs = [&](T(&f)[Q], unsigned id, unsigned m, bool& fullway) {
     const unsigned kind = kind_fast(a, id);
-    const T* val = bcval + slot_of(a, id) * 32u;
+    const unsigned vbase = slot_of(a, id) * 32u;
+    // (each branch reads the table through its own opaque index: identical LDS reads in two branches would be
+    // hoisted above them and stay live in the fluid path)
     if (kind == K_EQ) {
+      const T* val = bcval + opaque(vbase);
       static_for<Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
     } else if (kind == K_HW) {
+      const T* val = bcval + opaque(vbase);
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         if ((m >> l) & 1u) f[l] = f[l] + val[l];  // f[l] already is f_pre[opp l]; + moving-wall term (0 for no-slip)
@@ -182,10 +193,30 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
-  auto finish_a = [&](const S(&raw)[Q], unsigned w, int slot) {
+  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, int slot) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
+    if constexpr (HASBC != 0) {
+      const unsigned id = w & 0xffu, m = w >> 8;
+      if (id != 0u) {
+        const unsigned kind = kind_fast(a, id);
+        const bool hw = kind == K_HW, dn = kind == K_DN;
+        if (hw || dn) {
+          // the fix-up loads are invisible to the compiler: wait for them here (boundary lanes' waves only)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<Q>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if (dn || ((m >> l) & 1u)) {
+              S v = fix[l];
+              asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
+              f[l] = to_compute<T, S>(v);
+            }
+          });
+        }
+      }
+    }
     bool fullway = false;
     if constexpr (HASBC != 0) {
       if ((w & 0xffu) != 0u) bc_regs(f, w & 0xffu, w >> 8, fullway);
@@ -248,17 +279,17 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   };
 
   // Plane p lives in slot (p + 1) % 3 (p = -1 is the periodic image nx - 1).
-  S raw[Q];
+  S raw[Q], fix[Q];
   unsigned w_raw = 0;
   // prologue: planes -1, 0, 1 straight into the window (synchronous), then the pulls of plane 2 go in flight
   for (int p = -1; p <= 1; ++p) {
     if constexpr (HASBC != 0) w_raw = meta_load(wrapx(p), cell_a);
-    issue_a(wrapx(p), raw, w_raw);
+    issue_a(wrapx(p), raw, fix, w_raw);
     if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
-    finish_a(raw, w_raw, (p + 1) % 3);
+    finish_a(raw, fix, w_raw, (p + 1) % 3);
   }
   if constexpr (HASBC != 0) w_raw = meta_load(wrapx(2), cell_a);
-  issue_a(wrapx(2), raw, w_raw);
+  issue_a(wrapx(2), raw, fix, w_raw);
   lds_barrier();
   // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
   // The last two trips prefetch planes nx + 1, nx + 2 (periodic images, discarded): 2 / nx extra work, no branch.
@@ -267,9 +298,9 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
     phase_b(x, x % 3, (x + 1) % 3, (x + 2) % 3);
     lds_barrier();  // every reader of the slot about to be overwritten (plane x - 1) is done
-    finish_a(raw, w_raw, x % 3);  // plane x + 2 -> slot (x + 3) % 3
+    finish_a(raw, fix, w_raw, x % 3);  // plane x + 2 -> slot (x + 3) % 3
     w_raw = wa;
-    issue_a(wrapx(x + 3), raw, w_raw);
+    issue_a(wrapx(x + 3), raw, fix, w_raw);
     lds_barrier();  // plane x + 2 visible
   }
 }
