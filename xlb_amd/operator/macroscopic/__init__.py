@@ -1,1 +1,3 @@
+"""Moment operators of the HIP backend: density, velocity, momentum flux."""
+
 from .macroscopic import Macroscopic as Macroscopic, ZeroMoment as ZeroMoment, FirstMoment as FirstMoment, SecondMoment as SecondMoment
