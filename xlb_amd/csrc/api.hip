@@ -122,8 +122,9 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["block_tz"] = 0;         // threads along z per block (0 = a whole row when it fits)
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
   c->opts["smagorinsky_coef_e6"] = 170000;  // Smagorinsky constant x 1e6 for the STAND-ALONE collision operator (0.17)
-  c->opts["fuse2"] = 1;            // xlbhip_run: two steps per pass (step2_kernel.hpp): 0 never, 1 steppers without BCs, 2 also with BCs
+  c->opts["fuse2"] = 1;            // xlbhip_run: two steps per pass (step2_kernel.hpp): 0 never, 1 where eligible and the grid fills the chip, 2 wherever eligible
   c->opts["fuse2_tile"] = 0;       // z extent of the two-step tile: 0/64 -> 8x64, 32 -> 8x32 (two blocks per CU), 16 -> 16x16
+  c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
@@ -579,6 +580,7 @@ struct xlbhip_stepper {
   uint8_t* tab_kind = nullptr;  // device [256]
   unsigned long long ids_packed = 0;
   unsigned kinds_packed = 0;
+  unsigned moving_mask = 0;     // slots (first 8 BCs) whose halfway wall has a non-zero moving-wall term
   void* tab_values = nullptr;   // device [256][27] compute dtype
 };
 
@@ -627,6 +629,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
   p.meta = nullptr;
   p.tile_order = nullptr;
+  p.x_segments = 1;
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -656,12 +659,25 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   return p;
 }
 
+// x segments per tile column of the two-step kernel: finer work items balance the expensive hull tiles of
+// wall-bounded domains (measured at 512^3: 4-8 segments best; each costs 3 warm-up planes)
+static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
+  const int64_t xseg = opt(s->ctx, "fuse2_xseg", 0);
+  int n = xseg > 0 ? (int)xseg : 4;
+  while (n > 1 && p.nx / n < 32) n /= 2;
+  return n;
+}
+
 // two steps in one pass (a -> scratch-free: src -> dst holds f(t+2)); caller checked eligibility
 static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                       double omega) {
   StepLaunch p = make_launch(s, src, dst, bcm, miss, omega);
   p.meta = s->meta;
-  p.tile_order = (p.has_bc && opt(s->ctx, "fuse2_lpt", 1)) ? s->tile_order : nullptr;
+  // hull tiles first only pays when they are much more expensive than fluid tiles (halfway walls: redirected
+  // loads); with fullway / equilibrium boundaries the XCD-compact order is faster (fuse2_lpt: 0 never, 1 auto, 2 always)
+  const int64_t lpt = opt(s->ctx, "fuse2_lpt", 1);
+  p.tile_order = (p.has_bc && (lpt == 2 || (lpt == 1 && s->needs_missing))) ? s->tile_order : nullptr;
+  p.x_segments = fuse2_segments(s, p);
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   p.block_tz = (int)opt(s->ctx, "fuse2_tile", 0);
   return launch_step2_d3q19_bgk(p);
@@ -671,17 +687,20 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   const int64_t mode = opt(s->ctx, "fuse2", 1);
   if (mode == 0 || s->forced) return false;
   StepLaunch p = make_launch(s, src, dst, bcm, miss, 1.0);
-  // mode 1 (default): only steppers without boundary conditions — there the two-step kernel is 1.35x faster;
-  // its boundary-condition variant is correct but currently slower than two single steps, so it
-  // has to be asked for explicitly (mode 2)
-  if (mode == 1 && p.has_bc != 0) return false;
   if (!step2_eligible(p, s->lattice, s->collision)) return false;
   if (mode == 1) {
-    // one block per CU marches a whole (8 x 64) tile column: the grid must fill the chip in whole rounds
-    // (256^3 = 128 tiles would leave half of the 256 CUs idle; measured slower than the single-step kernel)
-    const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
-    const long rounds = (tiles + cus - 1) / cus;
-    if (tiles * 100 < rounds * cus * 85) return false;
+    // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
+    // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
+    const long items = (long)(p.ny / 8) * (p.nz / 64) * fuse2_segments(s, p), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
+    const long rounds = (items + cus - 1) / cus;
+    if (items * 100 < rounds * cus * 85) return false;
+    // halfway walls make the hull tiles ~1.7x as expensive as fluid tiles; with too many of them (256^3: 53 %)
+    // two single steps are faster (measured: 31.5 vs 37.0 GLUPS), at 384^3 (36 %) and 512^3 (27 %) fusing wins
+    if (s->needs_missing) {
+      const long tys = p.ny / 8, tzs = p.nz / 64;
+      const long hull = tys * tzs - (tys > 2 ? tys - 2 : 0) * (tzs > 2 ? tzs - 2 : 0);
+      if (hull * 100 > tys * tzs * 40) return false;
+    }
   }
   return true;
 }
@@ -754,9 +773,13 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   }
   unsigned long long ids_packed = 0;
   unsigned kinds_packed = 0;
+  unsigned moving_mask = 0;
   for (int i = 0; i < n_bc && i < 8; ++i) {
     ids_packed |= (unsigned long long)(bcs[i].id & 0xff) << (8 * i);
     kinds_packed |= (unsigned)(bcs[i].kind & 0xf) << (4 * i);
+    if (bcs[i].kind == XLBHIP_BC_HALFWAY_BB)
+      for (int l = 0; l < q; ++l)
+        if (bcs[i].values[l] != 0.0) moving_mask |= 1u << i;
   }
   XLB_HIP(hipSetDevice(c->device));
   xlbhip_stepper* s = new xlbhip_stepper();
@@ -770,6 +793,7 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   s->extended_bcs = extended;
   s->ids_packed = ids_packed;
   s->kinds_packed = kinds_packed;
+  s->moving_mask = moving_mask;
   XLB_HIP(hipMalloc(&s->tab_kind, 256));
   XLB_HIP(hipMemcpy(s->tab_kind, kind.data(), 256, hipMemcpyHostToDevice));
   if (cdt == XLBHIP_F32) {
@@ -860,7 +884,8 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
         s->order_tz = tzs;
       }
       hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, s->ctx->stream, static_cast<const uint8_t*>(bcm->data),
-                         miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells);
+                         miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,
+                         s->moving_mask);
       XLB_HIP(hipGetLastError());
     }
     // choose the number of pairs so that the remaining single steps land the result in the right buffer:

@@ -268,10 +268,26 @@ __global__ void k_copy(const V* __restrict__ src, V* __restrict__ dst, size_t n)
   if (i < n) __builtin_nontemporal_store(src[i], dst + i);
 }
 
-// meta word of the two-step kernel: bc id | missing bit-set << 8 (D3Q19: 19 bits)
-__global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* meta, size_t n) {
+// meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table:
+//   bits 0-3 kind (0 fluid, XLBHIP_BC_* for the basic kinds, 9 = halfway wall WITH a moving-wall term),
+//   bits 4-7 slot of the BC in the stepper's packed tables, bits 8.. missing bit-set (D3Q19: 19 bits)
+__global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* meta, size_t n, unsigned long long ids_packed,
+                             unsigned kinds_packed, unsigned moving_mask) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) meta[i] = (uint32_t)bc[i] | ((miss ? miss[i] : 0u) << 8);
+  if (i >= n) return;
+  const unsigned id = bc[i];
+  unsigned w = 0;
+  if (id != 0u) {
+    unsigned kind = 0, slot = 0;
+    for (int s = 0; s < 8; ++s)
+      if (((unsigned)(ids_packed >> (8 * s)) & 0xffu) == id) {
+        kind = (kinds_packed >> (4 * s)) & 0xfu;
+        slot = (unsigned)s;
+      }
+    if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 9u;
+    w = kind | (slot << 4) | ((miss ? miss[i] : 0u) << 8);
+  }
+  meta[i] = w;
 }
 
 template <class E>

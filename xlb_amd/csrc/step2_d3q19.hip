@@ -5,6 +5,9 @@
 namespace xlb {
 
 bool step2_eligible(const StepLaunch& p, int lattice, int collision) {
+  // do-nothing BCs would need a second redirected-load form (own cell, same population): not built, single-step kernel instead
+  for (int i = 0; i < p.n_bc && i < 8; ++i)
+    if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING) return false;
   return lattice == XLBHIP_D3Q19 && collision == XLBHIP_BGK && p.compute_dtype == XLBHIP_F32 && p.store_dtype == XLBHIP_F32 &&
          p.halo == 0 && p.has_bc <= 1 && p.n_bc <= MAX_FAST_BCS &&
          p.plane_stride >= (size_t)p.nx * p.ny * p.nz + 64 /* idle-wave stores land in the padding */ && p.ny % 8 == 0 && p.nz % 64 == 0 && p.nx >= 1;
@@ -19,6 +22,7 @@ static int launch2(const StepLaunch& p) {
   a.miss = p.miss;
   a.meta = p.meta;
   a.tile_order = (TY == 8 && TZ == 64) ? p.tile_order : nullptr;
+  a.x_segments = (p.x_segments > 1 && p.nx >= 8 * p.x_segments) ? p.x_segments : 1;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const float*>(p.tab_values);
   a.ids_packed = p.ids_packed;
@@ -36,7 +40,7 @@ static int launch2(const StepLaunch& p) {
   a.extra.smag_cs = p.smag_cs;
   const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
   a.xcd_swizzle = (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0;
-  hipLaunchKernelGGL((k_step2<D3Q19, float, float, XLBHIP_BGK, HASBC, TY, TZ>), dim3(tiles), dim3(S2Geom<TY, TZ>::THREADS), 0, p.stream, a);
+  hipLaunchKernelGGL((k_step2<D3Q19, float, float, XLBHIP_BGK, HASBC, TY, TZ>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<TY, TZ>::THREADS), 0, p.stream, a);
   XLB_HIP(hipGetLastError());
   return 0;
 }

@@ -36,6 +36,11 @@ struct S2Geom {
 // next plane, asynchronous stores of the finished one) at each of the two barriers per plane.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// meta word (built per run by k_build_meta): kind | slot << 4 | missing << 8
+constexpr unsigned K_HW_MOVING = 9;
+__device__ __forceinline__ unsigned meta_kind(unsigned w) { return w & 0xfu; }
+__device__ __forceinline__ unsigned meta_slot(unsigned w) { return (w >> 4) & 0xfu; }
+
 // slot (0..7) of a bc id in the packed kernel arguments; ids beyond the first 8 make the stepper ineligible
 template <class T, class S>
 __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id) {
@@ -61,14 +66,19 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   // tile of this block: from the launch's order table when there is one (hull tiles first — with boundary
   // conditions they are the expensive ones, and a CU that starts with one should get a cheap one next), else
   // a compact patch of tiles per XCD (blocks b and b + 8 share an XCD)
-  const unsigned tiles_z = (unsigned)a.nz / TZ, tiles_y = (unsigned)a.ny / TY;
-  unsigned tile = blockIdx.x;
+  const unsigned tiles_z = (unsigned)a.nz / TZ, tiles_y = (unsigned)a.ny / TY, n_tiles = tiles_y * tiles_z;
+  // a tile column may be cut into x segments (finer work items -> better balance when hull tiles are expensive);
+  // each segment warms its own 3-plane window up, so the result does not depend on the cut
+  const unsigned seg = blockIdx.x / n_tiles, slot_in_seg = blockIdx.x % n_tiles;
+  unsigned tile = slot_in_seg;
   if (a.tile_order) {
-    tile = a.tile_order[blockIdx.x];
+    tile = a.tile_order[slot_in_seg];
   } else if (a.xcd_swizzle) {
-    const unsigned per_xcd = (tiles_y * tiles_z) / 8u;  // launcher guarantees divisibility
-    tile = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    const unsigned per_xcd = n_tiles / 8u;  // launcher guarantees divisibility
+    tile = (slot_in_seg % 8u) * per_xcd + slot_in_seg / 8u;
   }
+  const int n_seg = a.x_segments > 0 ? a.x_segments : 1;
+  const int x_lo = (int)(((long)a.nx * seg) / n_seg), x_hi = (int)(((long)a.nx * (seg + 1)) / n_seg);
   const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
   const int t = threadIdx.x;
   const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -155,60 +165,86 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       // directions; do-nothing: own cell, same population) go out as inline-asm loads into fix[]: hipcc's
       // s_waitcnt bookkeeping does not see them, so this divergent region leaves the vmcnt model of the
       // steady-state loop exact (see the note above).  finish_a waits for them by hand.
-      const unsigned id = w & 0xffu, m = w >> 8;
-      if (id != 0u) {
-        const unsigned kind = kind_fast(a, id);
-        const bool hw = kind == K_HW, dn = kind == K_DN;
-        if (hw || dn) {
-          static_for<Q>([&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            if (dn || ((m >> l) & 1u)) {
-              const S* p = a.src + (size_t)(dn ? l : opp<L>(l)) * a.plane_stride + (size_t)x * plane_cells + cell_a;
-              S got;
-              asm volatile("global_load_dword %0, %1, off" : "=v"(got) : "v"(p) : "memory");
-              fix[l] = got;
-            }
-          });
-        }
+      const unsigned kind = meta_kind(w), m = w >> 8;
+      if (kind == K_HW || kind == K_HW_MOVING) {
+        const unsigned voff = cell_a * ES;
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          // wave-uniform skip: a z-face wave redirects 5 of the 19 populations, the other 14 cost one ballot each
+          if (__builtin_amdgcn_ballot_w64((m >> l) & 1u) == 0ull) return;
+          if ((m >> l) & 1u) {
+            // uniform (SGPR) base + one 32-bit lane offset: no per-lane 64-bit address arithmetic.
+            // ONE asm statement per population whose output IS fix[l]: any compiler-inserted copy of an
+            // asm-loaded register before the hand-placed wait would read stale data (guide section 5.7), so
+            // there is no initialiser, no second writer and no select on `got`
+            // (tests/test_gpu_stepper.py::test_two_step_fusion_matches_oracle guards this).
+            const S* b_opp = a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)x * plane_cells;
+            S got;
+#ifdef S2_DEBUG_VISIBLE
+            got = ld(b_opp, voff);
+#else
+            // s_nop 4: hipcc's hazard recognizer cannot see inside the string; the base may have just been written
+            // by a VALU (v_readlane of a spilled SGPR / v_readfirstlane), which needs 5 wait states before a VMEM
+            // instruction reads it — without them the load used a garbage address (memory fault on y-walls)
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(got) : "v"(voff), "s"(b_opp) : "memory");
+#endif
+            fix[l] = got;
+          }
+        });
       }
     }
   };
   // boundary treatment on registers: f holds the (redirected) pulls
-  auto bc_regs = [&](T(&f)[Q], unsigned id, unsigned m, bool& fullway) {
-    const unsigned kind = kind_fast(a, id);
-    const unsigned vbase = slot_of(a, id) * 32u;
+  auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) {
+    const unsigned kind = meta_kind(w), m = w >> 8;
+    const unsigned vbase = meta_slot(w) * 32u;
     // (each branch reads the table through its own opaque index: identical LDS reads in two branches would be
     // hoisted above them and stay live in the fluid path)
     if (kind == K_EQ) {
       const T* val = bcval + opaque(vbase);
       static_for<Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
     } else if (kind == K_HW) {
+      // no-slip wall: f[l] already is f_pre[opp l]; the reference still adds its 0.0 moving-wall term
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if ((m >> l) & 1u) f[l] = f[l] + T(0);
+      });
+    } else if (kind == K_HW_MOVING) {
       const T* val = bcval + opaque(vbase);
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        if ((m >> l) & 1u) f[l] = f[l] + val[l];  // f[l] already is f_pre[opp l]; + moving-wall term (0 for no-slip)
+        if ((m >> l) & 1u) f[l] = f[l] + val[l];
       });
     } else if (kind == K_FW) {
       fullway = true;
     }
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
-  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, int slot) {
+  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, int slot, bool steady) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
     if constexpr (HASBC != 0) {
-      const unsigned id = w & 0xffu, m = w >> 8;
-      if (id != 0u) {
-        const unsigned kind = kind_fast(a, id);
-        const bool hw = kind == K_HW, dn = kind == K_DN;
-        if (hw || dn) {
-          // the fix-up loads are invisible to the compiler: wait for them here (boundary lanes' waves only)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned kind = meta_kind(w), m = w >> 8;
+      {
+        const bool hw = kind == K_HW || kind == K_HW_MOVING;
+        if (hw) {
+          // The fix-up loads are invisible to the compiler: wait for them here (boundary lanes' waves only).
+          // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
+          // stores of the phase B that just ran (waves that own output cells) and possibly the meta prefetch,
+          // so vmcnt(Q) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
+          // which made hull tiles 3x slower than fluid tiles).  Extra younger operations only make this safer.
+          static_assert(Q == 19, "vmcnt immediate below assumes 19 stores per phase-B thread");
+          // (in the prologue no phase B has run yet: nothing younger, so drain everything)
+          if (steady && __builtin_amdgcn_readfirstlane(t) < G::NB)
+            asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           static_for<Q>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
-            if (dn || ((m >> l) & 1u)) {
+            if (__builtin_amdgcn_ballot_w64((m >> l) & 1u) == 0ull) return;
+            if ((m >> l) & 1u) {
               S v = fix[l];
               asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
               f[l] = to_compute<T, S>(v);
@@ -219,7 +255,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if ((w & 0xffu) != 0u) bc_regs(f, w & 0xffu, w >> 8, fullway);
+      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
     }
     finish(f, fullway);
     if (act_a) {
@@ -241,31 +277,37 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     base[2] = lds + slot_m * (Q * NE);
     unsigned w = 0;
     if constexpr (HASBC != 0) w = ldsmeta[slot_0 * NE + ctr_b];
-    const unsigned id = w & 0xffu, m = w >> 8;
+    const unsigned m = w >> 8;
     T f[Q];
-    bool wave_has_bc = false;
-    if constexpr (HASBC != 0) wave_has_bc = __builtin_amdgcn_ballot_w64(id != 0u) != 0ull;  // wave-uniform
-    if (!wave_has_bc) {
+    bool hw = false, wave_redirects = false;
+    if constexpr (HASBC != 0) {
+      const unsigned kind = meta_kind(w);
+      hw = kind == K_HW || kind == K_HW_MOVING;
+      wave_redirects = __builtin_amdgcn_ballot_w64(hw) != 0ull;  // wave-uniform: some lane reads its own cell instead
+    }
+    if (!wave_redirects) {
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
         f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
       });
     } else if constexpr (HASBC != 0) {
-      const unsigned kind = (id != 0u) ? kind_fast(a, id) : (unsigned)K_NONE;
-      const bool hw = kind == K_HW, dn = kind == K_DN;
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        int idx = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
-        if (hw && ((m >> l) & 1u)) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
-        if (dn) idx = slot_0 * (Q * NE) + l * NE + ctr_b;
-        f[l] = lds[idx];
+        const bool redirect = hw && ((m >> l) & 1u);
+        if (__builtin_amdgcn_ballot_w64(redirect) == 0ull) {  // wave-uniform: nobody redirects this population
+          f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
+        } else {
+          int idx = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
+          if (redirect) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
+          f[l] = lds[idx];
+        }
       });
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (id != 0u) bc_regs(f, id, m, fullway);
+      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
     }
     finish(f, fullway);
     if (act_b) {  // wave-uniform: NB is a whole number of waves
@@ -282,23 +324,25 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   S raw[Q], fix[Q];
   unsigned w_raw = 0;
   // prologue: planes -1, 0, 1 straight into the window (synchronous), then the pulls of plane 2 go in flight
+  // (slots are keyed on the offset from x_lo: plane x_lo + d lives in slot (d + 1) % 3)
   for (int p = -1; p <= 1; ++p) {
-    if constexpr (HASBC != 0) w_raw = meta_load(wrapx(p), cell_a);
-    issue_a(wrapx(p), raw, fix, w_raw);
+    if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + p), cell_a);
+    issue_a(wrapx(x_lo + p), raw, fix, w_raw);
     if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
-    finish_a(raw, fix, w_raw, (p + 1) % 3);
+    finish_a(raw, fix, w_raw, (p + 1) % 3, false);
   }
-  if constexpr (HASBC != 0) w_raw = meta_load(wrapx(2), cell_a);
-  issue_a(wrapx(2), raw, fix, w_raw);
+  if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + 2), cell_a);
+  issue_a(wrapx(x_lo + 2), raw, fix, w_raw);
   lds_barrier();
   // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
   // The last two trips prefetch planes nx + 1, nx + 2 (periodic images, discarded): 2 / nx extra work, no branch.
-  for (int x = 0; x < nx; ++x) {
+  for (int x = x_lo; x < x_hi; ++x) {
+    const int d = x - x_lo;
     unsigned wa = 0;
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
-    phase_b(x, x % 3, (x + 1) % 3, (x + 2) % 3);
+    phase_b(x, d % 3, (d + 1) % 3, (d + 2) % 3);
     lds_barrier();  // every reader of the slot about to be overwritten (plane x - 1) is done
-    finish_a(raw, fix, w_raw, x % 3);  // plane x + 2 -> slot (x + 3) % 3
+    finish_a(raw, fix, w_raw, d % 3, true);  // plane x + 2 -> slot (d + 3) % 3
     w_raw = wa;
     issue_a(wrapx(x + 3), raw, fix, w_raw);
     lds_barrier();  // plane x + 2 visible

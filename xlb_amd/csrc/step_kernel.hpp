@@ -38,6 +38,7 @@ struct StepArgs {
   const uint8_t* bc;      // (nx+2h, ny, nz) or nullptr
   const uint32_t* miss;   // (nx+2h, ny, nz) bit-sets or nullptr
   const uint32_t* tile_order;  // two-step kernel only: block -> tile, or nullptr
+  int x_segments;              // two-step kernel only: x cuts per tile column (>= 1)
   const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
   const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS

@@ -13,6 +13,7 @@ struct StepLaunch {
   const uint32_t* miss;
   const uint32_t* meta;  // two-step kernel only
   const uint32_t* tile_order;  // two-step kernel only
+  int x_segments;              // two-step kernel only
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
   unsigned long long ids_packed;
@@ -57,6 +58,7 @@ int launch_typed(const StepLaunch& p) {
   a.miss = p.miss;
   a.meta = nullptr;
   a.tile_order = nullptr;
+  a.x_segments = 1;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const T*>(p.tab_values);
   a.ids_packed = p.ids_packed;
