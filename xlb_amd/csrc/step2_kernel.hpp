@@ -41,6 +41,21 @@ constexpr unsigned K_HW_MOVING = 9;
 __device__ __forceinline__ unsigned meta_kind(unsigned w) { return w & 0xfu; }
 __device__ __forceinline__ unsigned meta_slot(unsigned w) { return (w >> 4) & 0xfu; }
 
+// Union over the wave of the missing bits of its halfway-wall lanes, as a UNIFORM (scalar) word: 0 for a fluid
+// wave; for a z-face wave 5 of 19 bits.  Every per-population boundary loop below tests it with scalar branches,
+// so a boundary wave pays for the populations it really redirects and one ballot pass per plane, not for 19
+// vector tests in four places (measured: hull tiles cost 1.7x a fluid tile before this).
+template <int Q>
+__device__ __forceinline__ unsigned wave_missing_union(bool hw, unsigned m) {
+  unsigned all = 0;
+  if (__builtin_amdgcn_ballot_w64(hw) != 0ull) {
+#pragma unroll
+    for (int l = 0; l < Q; ++l)
+      if (__builtin_amdgcn_ballot_w64(hw && ((m >> l) & 1u)) != 0ull) all |= 1u << l;
+  }
+  return all;
+}
+
 // slot (0..7) of a bc id in the packed kernel arguments; ids beyond the first 8 make the stepper ineligible
 template <class T, class S>
 __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id) {
@@ -148,7 +163,8 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   // Boundary lanes redirect a pull: a halfway wall reads the own cell's OPPOSITE population for its missing
   // directions, a do-nothing cell its own populations — same register, same number of loads, nothing
   // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
-  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w) {
+  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) {
+    mall = 0;
     if (!act_a) return;  // only the tail of the last wave is idle
     int Xs[3];
     Xs[0] = (x + 1 == nx) ? 0 : x + 1;
@@ -166,13 +182,14 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       // s_waitcnt bookkeeping does not see them, so this divergent region leaves the vmcnt model of the
       // steady-state loop exact (see the note above).  finish_a waits for them by hand.
       const unsigned kind = meta_kind(w), m = w >> 8;
-      if (kind == K_HW || kind == K_HW_MOVING) {
+      const bool hw = kind == K_HW || kind == K_HW_MOVING;
+      mall = wave_missing_union<Q>(hw, m);
+      if (mall != 0u) {
         const unsigned voff = cell_a * ES;
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
-          // wave-uniform skip: a z-face wave redirects 5 of the 19 populations, the other 14 cost one ballot each
-          if (__builtin_amdgcn_ballot_w64((m >> l) & 1u) == 0ull) return;
-          if ((m >> l) & 1u) {
+          if (((mall >> l) & 1u) == 0u) return;  // scalar
+          if (hw && ((m >> l) & 1u)) {
             // uniform (SGPR) base + one 32-bit lane offset: no per-lane 64-bit address arithmetic.
             // ONE asm statement per population whose output IS fix[l]: any compiler-inserted copy of an
             // asm-loaded register before the hand-placed wait would read stale data (guide section 5.7), so
@@ -195,7 +212,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
   };
   // boundary treatment on registers: f holds the (redirected) pulls
-  auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) {
+  auto bc_regs = [&](T(&f)[Q], unsigned w, unsigned mall, bool& fullway) {
     const unsigned kind = meta_kind(w), m = w >> 8;
     const unsigned vbase = meta_slot(w) * 32u;
     // (each branch reads the table through its own opaque index: identical LDS reads in two branches would be
@@ -207,12 +224,14 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       // no-slip wall: f[l] already is f_pre[opp l]; the reference still adds its 0.0 moving-wall term
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
+        if (((mall >> l) & 1u) == 0u) return;  // scalar
         if ((m >> l) & 1u) f[l] = f[l] + T(0);
       });
     } else if (kind == K_HW_MOVING) {
       const T* val = bcval + opaque(vbase);
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
+        if (((mall >> l) & 1u) == 0u) return;  // scalar
         if ((m >> l) & 1u) f[l] = f[l] + val[l];
       });
     } else if (kind == K_FW) {
@@ -220,7 +239,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
-  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, int slot, bool steady) {
+  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int slot, bool steady) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
@@ -243,7 +262,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
           __builtin_amdgcn_sched_barrier(0);
           static_for<Q>([&](auto lc) {
             constexpr int l = decltype(lc)::value;
-            if (__builtin_amdgcn_ballot_w64((m >> l) & 1u) == 0ull) return;
+            if (((mall >> l) & 1u) == 0u) return;  // scalar
             if ((m >> l) & 1u) {
               S v = fix[l];
               asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
@@ -255,7 +274,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
+      if (meta_kind(w) != 0u) bc_regs(f, w, mall, fullway);
     }
     finish(f, fullway);
     if (act_a) {
@@ -279,35 +298,35 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     if constexpr (HASBC != 0) w = ldsmeta[slot_0 * NE + ctr_b];
     const unsigned m = w >> 8;
     T f[Q];
-    bool hw = false, wave_redirects = false;
+    unsigned mall = 0;
+    bool hw = false;
     if constexpr (HASBC != 0) {
       const unsigned kind = meta_kind(w);
       hw = kind == K_HW || kind == K_HW_MOVING;
-      wave_redirects = __builtin_amdgcn_ballot_w64(hw) != 0ull;  // wave-uniform: some lane reads its own cell instead
+      mall = wave_missing_union<Q>(hw, m);  // uniform: populations some lane of this wave reads from its own cell
     }
-    if (!wave_redirects) {
+    if (mall == 0u) {  // fluid wave (or only fullway / equilibrium lanes): one scalar branch, then straight-line reads
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
         f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
       });
-    } else if constexpr (HASBC != 0) {
+    } else {
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        const bool redirect = hw && ((m >> l) & 1u);
-        if (__builtin_amdgcn_ballot_w64(redirect) == 0ull) {  // wave-uniform: nobody redirects this population
+        if (((mall >> l) & 1u) == 0u) {  // scalar
           f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
         } else {
           int idx = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
-          if (redirect) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
+          if (hw && ((m >> l) & 1u)) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
           f[l] = lds[idx];
         }
       });
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
+      if (meta_kind(w) != 0u) bc_regs(f, w, mall, fullway);
     }
     finish(f, fullway);
     if (act_b) {  // wave-uniform: NB is a whole number of waves
@@ -322,17 +341,17 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
 
   // Plane p lives in slot (p + 1) % 3 (p = -1 is the periodic image nx - 1).
   S raw[Q], fix[Q];
-  unsigned w_raw = 0;
+  unsigned w_raw = 0, mall_raw = 0;  // meta word / wave union of the plane held in raw
   // prologue: planes -1, 0, 1 straight into the window (synchronous), then the pulls of plane 2 go in flight
   // (slots are keyed on the offset from x_lo: plane x_lo + d lives in slot (d + 1) % 3)
   for (int p = -1; p <= 1; ++p) {
     if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + p), cell_a);
-    issue_a(wrapx(x_lo + p), raw, fix, w_raw);
+    issue_a(wrapx(x_lo + p), raw, fix, w_raw, mall_raw);
     if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
-    finish_a(raw, fix, w_raw, (p + 1) % 3, false);
+    finish_a(raw, fix, w_raw, mall_raw, (p + 1) % 3, false);
   }
   if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + 2), cell_a);
-  issue_a(wrapx(x_lo + 2), raw, fix, w_raw);
+  issue_a(wrapx(x_lo + 2), raw, fix, w_raw, mall_raw);
   lds_barrier();
   // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
   // The last two trips prefetch planes nx + 1, nx + 2 (periodic images, discarded): 2 / nx extra work, no branch.
@@ -342,9 +361,9 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
     phase_b(x, d % 3, (d + 1) % 3, (d + 2) % 3);
     lds_barrier();  // every reader of the slot about to be overwritten (plane x - 1) is done
-    finish_a(raw, fix, w_raw, d % 3, true);  // plane x + 2 -> slot (d + 3) % 3
+    finish_a(raw, fix, w_raw, mall_raw, d % 3, true);  // plane x + 2 -> slot (d + 3) % 3
     w_raw = wa;
-    issue_a(wrapx(x + 3), raw, fix, w_raw);
+    issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
     lds_barrier();  // plane x + 2 visible
   }
 }
