@@ -232,7 +232,9 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(args, world),
             "kernel": kernel,
-            "kernel_ms": round(step_ms, 4),
+            "kernel_ms": round(step_ms, 4),  # device time per STEP (HIP events / K)
+            "steps_per_launch": 2 if fused2 else 1,
+            "launch_ms": round(step_ms * (2 if fused2 else 1), 4),  # what rocprofv3 reports per kernel launch
             "algorithmic_bytes_per_update": b_alg,
             "copy_yardstick_gbs": None if copy_gbs is None else round(copy_gbs, 1),
         },
