@@ -226,11 +226,12 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": round(achieved, 1),
+            "achieved": round(achieved, 1),  # algorithmic bytes per launch / launch duration
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(args, world),
+            "traffic": measured_traffic(args, world, "k_step2" if fused2 else "k_step"),  # HBM bytes per launch (PMC)
+            "algorithmic_bytes_per_launch": b_alg * n**3 * (2 if fused2 else 1),
             "kernel": kernel,
             "kernel_ms": round(step_ms, 4),  # device time per STEP (HIP events / K)
             "steps_per_launch": 2 if fused2 else 1,
@@ -244,7 +245,7 @@ def main():
     print(json.dumps(out), flush=True)
 
 
-def measured_traffic(args, world):
+def measured_traffic(args, world, kernel):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), if one matches
     this exact workload; else null.  bench.py cannot collect counters on itself."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -255,7 +256,7 @@ def measured_traffic(args, world):
     except Exception:
         return None
     key = f"{args.lattice}_{args.collision}_{args.policy}_{args.workload}_{args.size}"
-    return table.get(key)
+    return (table.get(key) or {}).get(kernel)
 
 
 if __name__ == "__main__":
