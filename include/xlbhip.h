@@ -98,7 +98,8 @@ int xlbhip_lattice_info(int lattice, int* d, int* q, int32_t* c, double* w, int3
 
 /* ---- fields ------------------------------------------------------------- */
 /* replaces: WarpGrid.create_field, xlb/grid/warp_grid.py:17-35.
- * halo = number of ghost x-planes on each side (0, or 1 for slab-decomposed runs). */
+ * halo = number of ghost x-planes on each side: 0, or 1 / 2 for slab-decomposed runs (2 lets xlbhip_run fuse
+ * two steps per pass across rank boundaries). */
 int xlbhip_field_create(xlbhip_ctx* ctx, int cardinality, int nx, int ny, int nz, int dtype, int halo,
                         double fill_value, xlbhip_field** out);
 int xlbhip_field_destroy(xlbhip_field* f);
@@ -164,6 +165,15 @@ int xlbhip_step(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_ds
 /* n_steps steps with the A/B swap done natively; the result is in f_a if n_steps is even, else f_b */
 int xlbhip_run(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
                const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps);
+/* TWO steps in one pass (f(t) in f_src -> f(t+2) in f_dst, f(t+1) never reaches HBM): what xlbhip_run uses for
+ * pairs of steps where xlbhip_step2_eligible() says 1 (D3Q19 BGK fp32, basic BCs, ny % 8 == nz % 64 == 0, fields
+ * with 0 or 2 ghost planes, enough tiles to fill the chip).  Same arithmetic in the same order as two xlbhip_step
+ * calls (nse_stepper.py:237-282 twice): bit-identical results.  With the "external_halo" option the caller has
+ * filled f_src's ghost planes to depth 2 and the ghost planes of the masks to depth 1. */
+int xlbhip_step2_eligible(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_dst, const xlbhip_field* bc_mask,
+                          const xlbhip_field* missing_mask);
+int xlbhip_step2(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_dst, const xlbhip_field* bc_mask,
+                 const xlbhip_field* missing_mask, double omega, int64_t timestep);
 /* as xlbhip_run, bracketed by HIP events on the compute stream; returns device ms for the whole loop */
 int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
                      const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps,
@@ -180,6 +190,9 @@ int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_byte
 int xlbhip_comm_destroy(xlbhip_ctx* ctx);
 /* fill the ghost planes of f from the neighbours (blocking w.r.t. the compute stream order) */
 int xlbhip_halo_exchange(xlbhip_ctx* ctx, int lattice, xlbhip_field* f);
+/* the exchange a fused pair of steps needs (fields with 2 ghost planes): every population of the neighbours' edge
+ * planes and the face-crossing populations of the planes behind them */
+int xlbhip_halo_exchange_wide(xlbhip_ctx* ctx, int lattice, xlbhip_field* f);
 
 #ifdef __cplusplus
 }

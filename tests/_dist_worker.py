@@ -18,10 +18,10 @@ from oracle import xlb_numpy as orc  # noqa: E402
 from xlb_amd.distribute import SlabPlan  # noqa: E402
 
 
-def exchange(f_ext, plan):
+def exchange(f_ext, plan, messages=None):
     """Ring exchange of the face-crossing populations into the ghost planes (gloo p2p)."""
     reqs, recvs = [], []
-    for _, pops, send_plane, ghost_plane, send_peer, recv_peer in plan.messages():
+    for _, pops, send_plane, ghost_plane, send_peer, recv_peer in (plan.messages() if messages is None else messages):
         if send_peer is not None:
             buf = torch.from_numpy(np.ascontiguousarray(f_ext[pops, send_plane]))
             reqs.append(dist.isend(buf, dst=send_peer))
@@ -47,17 +47,34 @@ def main():
     f_glob = orc.perturbed_init(shape, lat, seed=13)
     expected = orc.run(f_glob, bc_mask, missing, bcs, 1.3, lat, steps)
 
-    plan = SlabPlan(shape[0], rank, world, lat.c[0])
+    depth = int(os.environ.get("XLB_TEST_DEPTH", "1"))
+    plan = SlabPlan(shape[0], rank, world, lat.c[0], halo=depth)
     x0, nxl = plan.x_offset, plan.nx_local
-    ext = lambda a: np.concatenate([np.zeros_like(a[:, :1]), a[:, x0 : x0 + nxl], np.zeros_like(a[:, :1])], axis=1)  # noqa: E731
+    h = depth
+    ghosts = lambda a: np.zeros_like(a[:, :h])  # noqa: E731
+    ext = lambda a: np.concatenate([ghosts(a), a[:, x0 : x0 + nxl], ghosts(a)], axis=1)  # noqa: E731
     f = ext(f_glob)
     bm, mm = ext(bc_mask), ext(missing)
-    for _ in range(steps):
-        exchange(f, plan)
-        new = orc.step(f, bm, mm, bcs, 1.3, lat)
-        f[:, 1:-1] = new[:, 1:-1]
+    if depth == 1:
+        for _ in range(steps):
+            exchange(f, plan)
+            new = orc.step(f, bm, mm, bcs, 1.3, lat)
+            f[:, 1:-1] = new[:, 1:-1]
+    else:
+        # what xlbhip_run does with two ghost planes: ONE exchange per PAIR of steps (SlabPlan.messages(2)), f(t+1)
+        # recomputed on the ghost planes -1 and nx — which takes the neighbours' boundary masks there (mask_messages)
+        exchange(bm, plan, plan.mask_messages())
+        exchange(mm, plan, [(t, np.arange(lat.q), s_, g, sp, rp) for t, _, s_, g, sp, rp in plan.mask_messages()])
+        assert steps % 2 == 0
+        for _ in range(steps // 2):
+            exchange(f, plan, plan.messages(2))
+            mid = orc.step(f, bm, mm, bcs, 1.3, lat)     # valid on planes -1 .. nx (the outermost ghosts wrap onto garbage)
+            mid[:, 0] = np.nan                             # poison what must not be used
+            mid[:, -1] = np.nan
+            new = orc.step(mid, bm, mm, bcs, 1.3, lat)   # valid on planes 0 .. nx - 1
+            f[:, h:-h] = new[:, h:-h]
     parts = [None] * world
-    dist.all_gather_object(parts, f[:, 1:-1])
+    dist.all_gather_object(parts, f[:, h:-h])
     got = np.concatenate(parts, axis=1)
     ok = np.array_equal(got, expected)
     flags = [None] * world

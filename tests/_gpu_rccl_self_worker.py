@@ -23,19 +23,26 @@ def main():
     init_hip("D3Q19")
     ctx = get_context()
     ctx.comm_init(0, 1, _lib.comm_unique_id())
-    shape = (12, 10, 16)
-    grid, bcs, lat, obcs = hip_cavity_3d(shape, HalfwayBounceBackBC, backend_config={"halo": True})
-    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
-    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
-    f_np = orc.perturbed_init(shape, lat, seed=8)
-    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
     ok = True
-    for overlap in (1, 0):
-        ctx.set_option("overlap", overlap)
-        f_0.assign(f_np)
-        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 9)
-        exp = orc.run(f_np, o_bm, o_mm, obcs, 1.5, lat, 9)
-        ok &= bool(np.array_equal(a.numpy(), exp))
+    # (12, 10, 16): single-step kernel with one or two ghost planes; (20, 16, 64): two-step kernel, depth-2 exchange
+    for shape, halo, fuse2 in (((12, 10, 16), 1, 1), ((12, 10, 16), 2, 1), ((20, 16, 64), 2, 2)):
+        ctx.set_option("fuse2", fuse2)
+        grid, bcs, lat, obcs = hip_cavity_3d(shape, HalfwayBounceBackBC, backend_config={"halo": halo})
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        if fuse2 == 2:
+            ok &= stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        f_np = orc.perturbed_init(shape, lat, seed=8)
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        for overlap in (1, 0):
+            ctx.set_option("overlap", overlap)
+            f_0.assign(f_np)
+            a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 9)
+            exp = orc.run(f_np, o_bm, o_mm, obcs, 1.5, lat, 9)
+            good = bool(np.array_equal(a.numpy(), exp))
+            if not good:
+                print(f"mismatch: shape {shape} halo {halo} fuse2 {fuse2} overlap {overlap}", flush=True)
+            ok &= good
     print("RCCL_SELF_OK" if ok else "RCCL_SELF_MISMATCH")
     sys.exit(0 if ok else 1)
 

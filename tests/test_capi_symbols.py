@@ -67,3 +67,24 @@ def test_lattice_tables_in_the_kernels_match_python_without_a_device():
         assert (d, q) == (vs.d, vs.q)
         assert np.array_equal(c[3 - d :], vs.c) and np.array_equal(w, vs._w) and np.array_equal(opp, vs.opp_indices)
         assert np.array_equal(cc[:, : vs._cc.shape[1]], vs._cc.astype(np.int32))
+
+
+def test_two_step_kernel_does_not_spill(tmp_path):
+    """k_step2 counts its outstanding vector-memory operations by hand (s_waitcnt vmcnt(19) behind inline-asm loads,
+    step2_kernel.hpp): a register spill adds scratch loads/stores the count does not know about and may copy a register
+    an asm load is still writing.  The kernel sits close to the SGPR/VGPR limits, so guard the compiled result."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "step2.s"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", f"-I{os.path.join(ROOT, 'include')}", "-S",
+           "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "xlb_amd", "csrc", "step2_d3q19.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    assert text.count("k_step2") > 0
+    assert "scratch_" not in text, "k_step2 spills to scratch"
+    sizes = [int(m) for m in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
+    assert sizes and all(v == 0 for v in sizes), sizes

@@ -22,9 +22,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,walls,lattice", [(2, orc.KIND_HALFWAY_BB, "D3Q19"), (2, orc.KIND_FULLWAY_BB, "D3Q19"), (3, orc.KIND_HALFWAY_BB, "D3Q27")])
-def test_slab_protocol_over_gloo(world, walls, lattice):
-    env = dict(os.environ, XLB_TEST_WALLS=walls, XLB_TEST_LATTICE=lattice, OMP_NUM_THREADS="1")
+@pytest.mark.parametrize("world,walls,lattice,depth", [
+    (2, orc.KIND_HALFWAY_BB, "D3Q19", 1), (2, orc.KIND_FULLWAY_BB, "D3Q19", 1), (3, orc.KIND_HALFWAY_BB, "D3Q27", 1),
+    # depth 2: one exchange per PAIR of steps, f(t+1) recomputed on the inner ghost planes (the two-step kernel's protocol)
+    (2, orc.KIND_HALFWAY_BB, "D3Q19", 2), (2, orc.KIND_FULLWAY_BB, "D3Q19", 2), (3, orc.KIND_HALFWAY_BB, "D3Q19", 2)])
+def test_slab_protocol_over_gloo(world, walls, lattice, depth):
+    env = dict(os.environ, XLB_TEST_WALLS=walls, XLB_TEST_LATTICE=lattice, XLB_TEST_DEPTH=str(depth), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -59,3 +62,22 @@ def test_slab_plan_matches_reference_ring():
             assert msgs["left"][4] == (r - 1) % world and msgs["left"][5] == (r + 1) % world
     p = SlabPlan(16, 0, 2, lat.c[0], periodic=False)
     assert p.has_right and not p.has_left
+
+
+def test_slab_plan_depth_two():
+    """Two fused steps: every population of the neighbour's edge plane + the crossing ones of the plane behind it;
+    storage planes shift with the number of ghost planes."""
+    lat = orc.Lattice("D3Q19")
+    p = SlabPlan(64, 1, 4, lat.c[0], halo=2)
+    nx = p.nx_local
+    one = {m[0]: m for m in p.messages(1)}
+    assert one["right"][2] == nx + 1 and one["right"][3] == 1 and one["left"][2] == 2 and one["left"][3] == nx + 2
+    two = {m[0]: m for m in p.messages(2)}
+    assert two["right"][1].tolist() == list(range(19)) and two["right"][2:4] == (nx + 1, 1)
+    assert two["right2"][1].tolist() == [14, 15, 16, 17, 18] and two["right2"][2:4] == (nx, 0)
+    assert two["left"][1].tolist() == list(range(19)) and two["left"][2:4] == (2, nx + 2)
+    assert two["left2"][1].tolist() == [9, 10, 11, 12, 13] and two["left2"][2:4] == (3, nx + 3)
+    assert all(m[4] == (2 if m[0].startswith("right") else 0) and m[5] == (0 if m[0].startswith("right") else 2) for m in p.messages(2))
+    assert [m[2:4] for m in p.mask_messages()] == [(nx + 1, 1), (2, nx + 2)]
+    with pytest.raises(ValueError):
+        SlabPlan(64, 1, 4, lat.c[0], halo=1).messages(2)

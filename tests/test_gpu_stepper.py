@@ -208,8 +208,9 @@ def test_ghost_plane_protocol_single_rank(walls_cls):
     """Fields with ghost x-planes + self ring exchange (the slab protocol on one rank) give the
     same bits as the plain periodic kernel, with and without interior/edge splitting."""
     results = []
-    for cfg in (None, {"halo": True}):
+    for cfg in (None, {"halo": 1}, {"halo": 2}):
         grid, bcs, lat, obcs = hip_cavity_3d((10, 8, 16), walls_cls, backend_config=cfg)
+        assert grid.halo == (cfg or {}).get("halo", 0)
         stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
         f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
         f_0.assign(orc.perturbed_init((10, 8, 16), lat, seed=3))
@@ -218,7 +219,7 @@ def test_ghost_plane_protocol_single_rank(walls_cls):
             f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.4, 3)
         get_context().set_option("overlap", 1)
         results.append(f_0.numpy())
-    assert np.array_equal(results[0], results[1])
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
 
 
 def test_stepper_argument_errors():
@@ -269,3 +270,43 @@ def test_two_step_fusion_matches_oracle(shape, walls_cls, steps):
         assert np.array_equal(out, exp), f"max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out - exp).max()}"
     finally:
         ctx.set_option("fuse2", 1)
+
+
+@pytest.mark.parametrize("shape", [(20, 8, 64), (16, 16, 64), (6, 8, 64)])
+@pytest.mark.parametrize("walls_cls", [None, FullwayBounceBackBC, HalfwayBounceBackBC])
+@pytest.mark.parametrize("steps", [2, 5, 8])
+def test_two_step_fusion_slab_protocol(shape, walls_cls, steps):
+    """The two-step kernel on fields with TWO ghost planes per side (the multi-rank layout) with the depth-2 ring
+    exchange onto the rank itself: interior launch overlapped with the exchange + two edge launches (nx >= 16), or one
+    launch after the exchange — same bits as the oracle on the periodic domain.  The x-walls of the cavity sit on the
+    slab faces, so boundary cells (halfway redirects, fullway swaps, the moving lid's corner cells) are evaluated on
+    the ghost planes as well."""
+    cfg = {"halo": 2}
+    if walls_cls is None:
+        vs, pp = init_hip("D3Q19")
+        lat = orc.Lattice("D3Q19")
+        grid = grid_factory(shape, backend_config=cfg)
+        bcs, obcs = [], []
+    else:
+        grid, bcs, lat, obcs = hip_cavity_3d(shape, walls_cls, backend_config=cfg)
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert f_0.halo == 2 and stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        f_np = orc.perturbed_init(shape, lat, seed=29)
+        if obcs:
+            o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        else:
+            o_bm, o_mm = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+        exp = orc.run(f_np, o_bm, o_mm, obcs, 1.6, lat, steps)
+        for overlap in (1, 0):
+            ctx.set_option("overlap", overlap)
+            f_0.assign(f_np)
+            a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.6, steps)
+            out = a.numpy()
+            assert np.array_equal(out, exp), f"overlap={overlap}: max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out - exp).max()}"
+    finally:
+        ctx.set_option("fuse2", 1)
+        ctx.set_option("overlap", 1)

@@ -77,6 +77,9 @@ SIGNATURES = {
     "xlbhip_comm_init": [_p, _i, _i, _p, _i],
     "xlbhip_comm_destroy": [_p],
     "xlbhip_halo_exchange": [_p, _i, _p],
+    "xlbhip_halo_exchange_wide": [_p, _i, _p],
+    "xlbhip_step2_eligible": [_p, _p, _p, _p, _p],
+    "xlbhip_step2": [_p, _p, _p, _p, _p, _d, _i64],
 }
 
 _lib = None
@@ -234,14 +237,19 @@ class Field:
         check(load().xlbhip_field_copy(self.handle, other.handle))
         return self
 
+    @property
+    def plane_dtype(self):
+        """dtype of one device x-plane: the field's dtype, or uint32 bit-sets for the bit-packed missing_mask (population 0)"""
+        return np.dtype(np.uint32) if self.dtype_code == MISSING else np.dtype(self.dtype)
+
     def get_plane(self, population, storage_plane):
-        """One x-plane (ny, nz) of one population; storage_plane counts the left ghost (if any) as 0."""
-        out = np.empty(self._s3[1:], dtype=self.dtype)
+        """One x-plane (ny, nz) of one population; storage_plane counts the left ghosts (if any) from 0."""
+        out = np.empty(self._s3[1:], dtype=self.plane_dtype)
         check(load().xlbhip_field_plane_download(self.handle, int(population), int(storage_plane), out.ctypes.data, out.nbytes))
         return out
 
     def set_plane(self, population, storage_plane, array):
-        a = np.ascontiguousarray(array, dtype=self.dtype)
+        a = np.ascontiguousarray(array, dtype=self.plane_dtype)
         assert a.shape == tuple(self._s3[1:])
         check(load().xlbhip_field_plane_upload(self.handle, int(population), int(storage_plane), a.ctypes.data, a.nbytes))
 
@@ -311,6 +319,13 @@ class Stepper:
 
     def step(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
         check(load().xlbhip_step(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
+
+    def step2_eligible(self, f_src, f_dst, bc_mask, missing_mask):
+        return bool(load().xlbhip_step2_eligible(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask)))
+
+    def step2(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
+        """Two steps in one pass: f(t) in f_src -> f(t+2) in f_dst."""
+        check(load().xlbhip_step2(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
 
     def run(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
         check(load().xlbhip_run(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),

@@ -123,7 +123,6 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["overlap"] = 1;          // halo exchange overlapped with the interior kernel
   c->opts["smagorinsky_coef_e6"] = 170000;  // Smagorinsky constant x 1e6 for the STAND-ALONE collision operator (0.17)
   c->opts["fuse2"] = 1;            // xlbhip_run: two steps per pass (step2_kernel.hpp): 0 never, 1 where eligible and the grid fills the chip, 2 wherever eligible
-  c->opts["fuse2_tile"] = 0;       // z extent of the two-step tile: 0/64 -> 8x64, 32 -> 8x32 (two blocks per CU), 16 -> 16x16
   c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
@@ -193,7 +192,7 @@ int xlbhip_lattice_info(int lattice, int* d, int* q, int32_t* c, double* w, int3
 int xlbhip_field_create(xlbhip_ctx* c, int card, int nx, int ny, int nz, int dtype, int halo, double fill, xlbhip_field** out) {
   XLB_REQUIRE(c && out, "null argument");
   XLB_REQUIRE(card >= 1 && nx >= 1 && ny >= 1 && nz >= 1, "bad field shape (%d,%d,%d,%d)", card, nx, ny, nz);
-  XLB_REQUIRE(halo == 0 || halo == 1, "halo must be 0 or 1");
+  XLB_REQUIRE(halo >= 0 && halo <= 2, "halo must be 0, 1 or 2");
   XLB_REQUIRE(dtype_size(dtype) > 0, "bad dtype %d", dtype);
   XLB_REQUIRE(dtype != XLBHIP_MISSING || card <= 32, "missing_mask cardinality %d > 32", card);
   XLB_HIP(hipSetDevice(c->device));
@@ -353,8 +352,8 @@ int xlbhip_field_download(const xlbhip_field* f, void* host, size_t bytes) {
 
 int xlbhip_field_plane_download(const xlbhip_field* f, int population, int storage_plane, void* host, size_t bytes) {
   XLB_REQUIRE(f && host, "null argument");
-  XLB_REQUIRE(f->dtype != XLBHIP_MISSING, "plane access is not defined for the bit-packed missing_mask");
-  XLB_REQUIRE(population >= 0 && population < f->card && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
+  // (the bit-packed missing_mask has ONE device plane of uint32 bit-sets: population 0)
+  XLB_REQUIRE(population >= 0 && population < f->planes && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
               "plane (%d, %d) out of range", population, storage_plane);
   const size_t es = dtype_size(f->dtype), plane = (size_t)f->ny * f->nz;
   XLB_REQUIRE(bytes == plane * es, "plane size %zu != %zu", bytes, plane * es);
@@ -366,8 +365,8 @@ int xlbhip_field_plane_download(const xlbhip_field* f, int population, int stora
 
 int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane, const void* host, size_t bytes) {
   XLB_REQUIRE(f && host, "null argument");
-  XLB_REQUIRE(f->dtype != XLBHIP_MISSING, "plane access is not defined for the bit-packed missing_mask");
-  XLB_REQUIRE(population >= 0 && population < f->card && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
+  // (the bit-packed missing_mask has ONE device plane of uint32 bit-sets: population 0)
+  XLB_REQUIRE(population >= 0 && population < f->planes && storage_plane >= 0 && storage_plane < f->nx + 2 * f->halo,
               "plane (%d, %d) out of range", population, storage_plane);
   const size_t es = dtype_size(f->dtype), plane = (size_t)f->ny * f->nz;
   XLB_REQUIRE(bytes == plane * es, "plane size %zu != %zu", bytes, plane * es);
@@ -664,7 +663,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
 static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
   const int64_t xseg = opt(s->ctx, "fuse2_xseg", 0);
   int n = xseg > 0 ? (int)xseg : 4;
-  while (n > 1 && p.nx / n < 32) n /= 2;
+  while (n > 1 && p.x_count / n < 32) n /= 2;
   return n;
 }
 
@@ -679,7 +678,30 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   p.tile_order = (p.has_bc && (lpt == 2 || (lpt == 1 && s->needs_missing))) ? s->tile_order : nullptr;
   p.x_segments = fuse2_segments(s, p);
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
-  p.block_tz = (int)opt(s->ctx, "fuse2_tile", 0);
+  xlbhip_ctx* c = s->ctx;
+  if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2_d3q19_bgk(p);
+  // slab protocol for a PAIR of steps: the two ghost planes per side of src are refilled on the comm stream
+  // (comm.cpp, depth 2) while the planes whose two-step cone stays inside the slab are updated; the two edge
+  // plane pairs follow (each warms its own 3-plane window up from the fresh ghosts).
+  const bool overlap = opt(c, "overlap", 1) != 0 && src->nx >= 16;
+  XLB_HIP(hipEventRecord(c->ev_edge, c->stream));  // src complete (previous pair)
+  XLB_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
+  if (int rc = halo_exchange_on(c, s->lattice, const_cast<xlbhip_field*>(src), c->comm_stream, 2)) return rc;
+  XLB_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
+  if (!overlap) {
+    XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    return launch_step2_d3q19_bgk(p);
+  }
+  p.x_begin = 2;
+  p.x_count = src->nx - 4;
+  p.x_segments = fuse2_segments(s, p);
+  if (int rc = launch_step2_d3q19_bgk(p)) return rc;
+  XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  p.x_segments = 1;
+  p.x_count = 2;
+  p.x_begin = 0;
+  if (int rc = launch_step2_d3q19_bgk(p)) return rc;
+  p.x_begin = src->nx - 2;
   return launch_step2_d3q19_bgk(p);
 }
 
@@ -703,6 +725,52 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     }
   }
   return true;
+}
+
+// per-run tables of the two-step kernel: the meta words (bc kind | slot | missing bits per cell, ghost planes
+// included) and the hull-first tile order
+static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhip_field* miss) {
+  if (!(s->n_bc > 0 && bcm)) return 0;
+  xlbhip_ctx* c = s->ctx;
+  const size_t cells = bcm->cells_with_halo();
+  if (s->meta_cells != cells) {
+    if (s->meta) XLB_HIP(hipFree(s->meta));
+    s->meta = nullptr;
+    XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
+    s->meta_cells = cells;
+  }
+  const int tys = bcm->ny / 8, tzs = bcm->nz / 64;
+  if (s->order_ty != tys || s->order_tz != tzs) {
+    // hull tiles first (the expensive ones when there are walls), then the interior in XCD-friendly order
+    std::vector<uint32_t> order;
+    order.reserve((size_t)tys * tzs);
+    for (int ty = 0; ty < tys; ++ty)
+      for (int tz = 0; tz < tzs; ++tz)
+        if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) order.push_back((uint32_t)(ty * tzs + tz));
+    std::vector<uint32_t> inner;
+    for (int ty = 1; ty < tys - 1; ++ty)
+      for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
+    const size_t n_in = inner.size(), per = (n_in + 7) / 8;
+    for (size_t i = 0; i < per * 8; ++i) {  // block i -> XCD i % 8 -> its contiguous chunk of the interior list
+      const size_t j = (i % 8) * per + i / 8;
+      if (j < n_in) order.push_back(inner[j]);
+    }
+    if (s->tile_order) XLB_HIP(hipFree(s->tile_order));
+    s->tile_order = nullptr;
+    XLB_HIP(hipMalloc(&s->tile_order, order.size() * sizeof(uint32_t)));
+    XLB_HIP(hipMemcpy(s->tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    s->order_ty = tys;
+    s->order_tz = tzs;
+  }
+  hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, c->stream, static_cast<const uint8_t*>(bcm->data),
+                     miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,
+                     s->moving_mask);
+  XLB_HIP(hipGetLastError());
+  // slab decomposition: phase A also runs on the ghost planes -1 and nx, so it needs the neighbours' boundary
+  // information there.  Host-staged transports (external_halo) fill the ghost planes of the masks themselves.
+  if (bcm->halo > 0 && !opt(c, "external_halo", 0))
+    return plane_exchange_on(c, s->meta, sizeof(uint32_t), bcm->nx, bcm->ny, bcm->nz, bcm->halo, c->stream);
+  return 0;
 }
 
 // one step src -> dst, with the slab halo protocol when the fields carry ghost planes
@@ -851,43 +919,10 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
   int64_t i = 0;
   xlbhip_field* cur = a;
   xlbhip_field* oth = b;
-  if (n >= 2 && can_fuse2(s, a, b, bcm, miss)) {
-    if (s->n_bc > 0 && bcm) {
-      const size_t cells = bcm->cells();
-      if (s->meta_cells != cells) {
-        if (s->meta) XLB_HIP(hipFree(s->meta));
-        s->meta = nullptr;
-        XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
-        s->meta_cells = cells;
-      }
-      const int tys = bcm->ny / 8, tzs = bcm->nz / 64;
-      if (s->order_ty != tys || s->order_tz != tzs) {
-        // hull tiles first (the expensive ones when there are walls), then the interior in XCD-friendly order
-        std::vector<uint32_t> order;
-        order.reserve((size_t)tys * tzs);
-        for (int ty = 0; ty < tys; ++ty)
-          for (int tz = 0; tz < tzs; ++tz)
-            if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) order.push_back((uint32_t)(ty * tzs + tz));
-        std::vector<uint32_t> inner;
-        for (int ty = 1; ty < tys - 1; ++ty)
-          for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
-        const size_t n_in = inner.size(), per = (n_in + 7) / 8;
-        for (size_t i = 0; i < per * 8; ++i) {  // block i -> XCD i % 8 -> its contiguous chunk of the interior list
-          const size_t j = (i % 8) * per + i / 8;
-          if (j < n_in) order.push_back(inner[j]);
-        }
-        if (s->tile_order) XLB_HIP(hipFree(s->tile_order));
-        s->tile_order = nullptr;
-        XLB_HIP(hipMalloc(&s->tile_order, order.size() * sizeof(uint32_t)));
-        XLB_HIP(hipMemcpy(s->tile_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        s->order_ty = tys;
-        s->order_tz = tzs;
-      }
-      hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, s->ctx->stream, static_cast<const uint8_t*>(bcm->data),
-                         miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,
-                         s->moving_mask);
-      XLB_HIP(hipGetLastError());
-    }
+  // (a host-staged transport refills the ghosts between calls: it drives pairs through xlbhip_step2 itself)
+  const bool caller_fills_ghosts = a->halo > 0 && opt(s->ctx, "external_halo", 0) != 0;
+  if (n >= 2 && !caller_fills_ghosts && can_fuse2(s, a, b, bcm, miss)) {
+    if (int rc = prepare_fuse2(s, bcm, miss)) return rc;
     // choose the number of pairs so that the remaining single steps land the result in the right buffer:
     // after P pairs the data sits in (P odd ? b : a); then r = n - 2P single steps flip r more times.
     // P + r must be congruent to n (mod 2)  <=>  P even.  Use the largest even P with 2P <= n.
@@ -910,6 +945,20 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
   return 0;
 }
 
+int xlbhip_step2_eligible(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
+  if (check_step_fields(s, src, dst, bcm, miss)) return 0;
+  return can_fuse2(s, src, dst, bcm, miss) ? 1 : 0;
+}
+
+int xlbhip_step2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+                 double omega, int64_t timestep) {
+  (void)timestep;
+  if (int rc = check_step_fields(s, src, dst, bcm, miss)) return rc;
+  XLB_REQUIRE(can_fuse2(s, src, dst, bcm, miss), "this stepper / field layout has no two-step kernel (see xlbhip_step2_eligible)");
+  if (int rc = prepare_fuse2(s, bcm, miss)) return rc;
+  return step_twice(s, src, dst, bcm, miss, omega);
+}
+
 int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
                      int64_t t0, int64_t n, float* ms) {
   XLB_REQUIRE(s && ms, "null argument");
@@ -924,9 +973,16 @@ int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const 
 
 int xlbhip_halo_exchange(xlbhip_ctx* c, int lattice, xlbhip_field* f) {
   XLB_REQUIRE(c && f, "null argument");
-  XLB_REQUIRE(f->halo == 1, "field has no ghost planes");
+  XLB_REQUIRE(f->halo >= 1, "field has no ghost planes");
   XLB_REQUIRE(f->card == lattice_q(lattice), "field cardinality does not match the lattice");
-  return halo_exchange_on(c, lattice, f, c->stream);
+  return halo_exchange_on(c, lattice, f, c->stream, 1);
+}
+
+int xlbhip_halo_exchange_wide(xlbhip_ctx* c, int lattice, xlbhip_field* f) {
+  XLB_REQUIRE(c && f, "null argument");
+  XLB_REQUIRE(f->halo >= 2, "field has fewer than two ghost planes per side");
+  XLB_REQUIRE(f->card == lattice_q(lattice), "field cardinality does not match the lattice");
+  return halo_exchange_on(c, lattice, f, c->stream, 2);
 }
 
 }  // extern "C"

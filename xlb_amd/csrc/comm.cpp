@@ -72,25 +72,20 @@ static void face_sets(std::vector<int>& right, std::vector<int>& left) {
   }
 }
 
-int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t st) {
-  XLB_REQUIRE(f->halo == 1, "halo exchange on a field without ghost planes");
-  std::vector<int> right, left;
-  if (lattice == XLBHIP_D3Q19)
-    face_sets<D3Q19>(right, left);
-  else if (lattice == XLBHIP_D3Q27)
-    face_sets<D3Q27>(right, left);
-  else
-    XLB_FAIL("slab decomposition needs a 3-D lattice");
-  const size_t es = dtype_size(f->dtype);
-  const size_t plane = (size_t)f->ny * f->nz;
-  const size_t bytes = plane * es;
-  auto ptr = [&](int l, int X) { return static_cast<char*>(f->data) + ((size_t)l * f->plane_stride + (size_t)X * plane) * es; };
-  const int nx = f->nx;
+// one plane-sized message of the ring: dir = +1 travels to the right neighbour (and the matching receive comes
+// from the left one), dir = -1 the other way
+struct HaloMsg {
+  const char* send;
+  char* recv;
+  int dir;
+};
+
+static int run_messages(xlbhip_ctx* c, const std::vector<HaloMsg>& msgs, size_t bytes, hipStream_t st) {
   Comm* cm = c->comm;
   if (!cm || !cm->comm) {
+    // single rank without a communicator: the ring neighbour is the field itself (periodic wrap)
     if (cm && !cm->periodic) return 0;
-    for (int l : right) XLB_HIP(hipMemcpyAsync(ptr(l, 0), ptr(l, nx), bytes, hipMemcpyDeviceToDevice, st));
-    for (int l : left) XLB_HIP(hipMemcpyAsync(ptr(l, nx + 1), ptr(l, 1), bytes, hipMemcpyDeviceToDevice, st));
+    for (const HaloMsg& m : msgs) XLB_HIP(hipMemcpyAsync(m.recv, m.send, bytes, hipMemcpyDeviceToDevice, st));
     return 0;
   }
   const int r = cm->rank, n = cm->n_ranks;
@@ -98,16 +93,63 @@ int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t st
   const bool has_right = cm->periodic || r + 1 < n;
   const bool has_left = cm->periodic || r > 0;
   XLB_NCCL(g_rccl.GroupStart());
-  for (int l : right) {
-    if (has_right) XLB_NCCL(g_rccl.Send(ptr(l, nx), bytes, ncclInt8, rr, cm->comm, st));
-    if (has_left) XLB_NCCL(g_rccl.Recv(ptr(l, 0), bytes, ncclInt8, lr, cm->comm, st));
-  }
-  for (int l : left) {
-    if (has_left) XLB_NCCL(g_rccl.Send(ptr(l, 1), bytes, ncclInt8, lr, cm->comm, st));
-    if (has_right) XLB_NCCL(g_rccl.Recv(ptr(l, nx + 1), bytes, ncclInt8, rr, cm->comm, st));
+  for (const HaloMsg& m : msgs) {
+    if (m.dir > 0) {
+      if (has_right) XLB_NCCL(g_rccl.Send(m.send, bytes, ncclInt8, rr, cm->comm, st));
+      if (has_left) XLB_NCCL(g_rccl.Recv(m.recv, bytes, ncclInt8, lr, cm->comm, st));
+    } else {
+      if (has_left) XLB_NCCL(g_rccl.Send(m.send, bytes, ncclInt8, lr, cm->comm, st));
+      if (has_right) XLB_NCCL(g_rccl.Recv(m.recv, bytes, ncclInt8, rr, cm->comm, st));
+    }
   }
   XLB_NCCL(g_rccl.GroupEnd());
   return 0;
+}
+
+int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t st, int depth) {
+  XLB_REQUIRE(depth == 1 || depth == 2, "halo depth must be 1 or 2");
+  XLB_REQUIRE(f->halo >= depth, "halo exchange of depth %d on a field with %d ghost plane(s)", depth, f->halo);
+  XLB_REQUIRE(f->nx >= depth, "slab thinner than the halo");
+  std::vector<int> right, left;
+  int q = 0;
+  if (lattice == XLBHIP_D3Q19) {
+    face_sets<D3Q19>(right, left);
+    q = D3Q19::Q;
+  } else if (lattice == XLBHIP_D3Q27) {
+    face_sets<D3Q27>(right, left);
+    q = D3Q27::Q;
+  } else {
+    XLB_FAIL("slab decomposition needs a 3-D lattice");
+  }
+  const size_t es = dtype_size(f->dtype);
+  const size_t plane = (size_t)f->ny * f->nz;
+  const int h = f->halo, nx = f->nx;
+  // interior plane X (ghosts: -h .. -1 and nx .. nx + h - 1) of population l
+  auto ptr = [&](int l, int X) { return static_cast<char*>(f->data) + ((size_t)l * f->plane_stride + (size_t)(X + h) * plane) * es; };
+  std::vector<HaloMsg> msgs;
+  if (depth == 1) {
+    // one step: only the populations that cross the face are pulled from the ghost plane
+    for (int l : right) msgs.push_back({ptr(l, nx - 1), ptr(l, -1), +1});
+    for (int l : left) msgs.push_back({ptr(l, 0), ptr(l, nx), -1});
+  } else {
+    // two fused steps: f(t+1) is recomputed on the ghost planes -1 and nx, which takes every population of the
+    // neighbour's edge plane (a halfway wall there may redirect any pull to the own cell) and the crossing
+    // populations of the plane behind it
+    for (int l = 0; l < q; ++l) msgs.push_back({ptr(l, nx - 1), ptr(l, -1), +1});
+    for (int l : right) msgs.push_back({ptr(l, nx - 2), ptr(l, -2), +1});
+    for (int l = 0; l < q; ++l) msgs.push_back({ptr(l, 0), ptr(l, nx), -1});
+    for (int l : left) msgs.push_back({ptr(l, 1), ptr(l, nx + 1), -1});
+  }
+  return run_messages(c, msgs, plane * es, st);
+}
+
+// ghost planes -1 and nx of a one-component per-cell array with `halo` ghost planes (the two-step kernel's meta words)
+int plane_exchange_on(xlbhip_ctx* c, void* base, size_t elem_bytes, int nx, int ny, int nz, int halo, hipStream_t st) {
+  XLB_REQUIRE(halo >= 1 && nx >= 1, "plane exchange needs ghost planes");
+  const size_t bytes = (size_t)ny * nz * elem_bytes;
+  auto ptr = [&](int X) { return static_cast<char*>(base) + (size_t)(X + halo) * bytes; };
+  std::vector<HaloMsg> msgs = {{ptr(nx - 1), ptr(-1), +1}, {ptr(0), ptr(nx), -1}};
+  return run_messages(c, msgs, bytes, st);
 }
 
 }  // namespace xlb

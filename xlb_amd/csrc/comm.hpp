@@ -5,5 +5,8 @@
 namespace xlb {
 // enqueue on `stream` the refill of f's two ghost planes from the ring neighbours (or from the
 // field itself when there is a single rank): populations with c_x = +1 travel "right", c_x = -1 "left".
-int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t stream);
+// depth 1: what one step pulls across the faces; depth 2: what two fused steps need (see comm.cpp)
+int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t stream, int depth = 1);
+// ghost planes -1 and nx of a per-cell array (nx + 2 halo planes of ny x nz elements)
+int plane_exchange_on(xlbhip_ctx* c, void* base, size_t elem_bytes, int nx, int ny, int nz, int halo, hipStream_t stream);
 }  // namespace xlb

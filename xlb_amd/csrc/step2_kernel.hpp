@@ -12,8 +12,10 @@
 // 2 + 2.  Arithmetic is the same per-cell code (cell.hpp) in the same order, so the result is
 // bit-identical to two single steps (tests/test_gpu_stepper.py::test_two_step_fusion_*).
 //
-// Restrictions (the launcher falls back to the single-step kernel otherwise): D3Q19; fp32 compute and store; no ghost planes (single rank); ny % TY == 0,
-// nz % TZ == 0; BGK / basic boundary conditions.
+// Restrictions (the launcher falls back to the single-step kernel otherwise): D3Q19; fp32 compute and store;
+// ny % TY == 0, nz % TZ == 0; BGK / basic boundary conditions; fields without ghost planes (x wraps here) or with
+// TWO ghost planes per side (slab decomposition: phase A also computes f(t+1) on the ghost planes -1 and nx from
+// the neighbours' f(t) — all populations of their edge plane and the inward-moving ones of the plane behind it).
 #pragma once
 #include "step_kernel.hpp"
 
@@ -68,7 +70,11 @@ __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id
   return slot;
 }
 
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ>
+// SLAB: the fields carry two ghost planes per side and the launcher passes src / dst / meta advanced to interior
+// plane 0, so that plane indices -2 .. nx + 1 address the ghosts directly and x never wraps.  (A compile-time
+// switch: the kernel sits at the SGPR limit — 19 uniform row bases per plane — and a run-time halo offset pushed
+// it into scratch spills, which also broke the hand-counted vmcnt of the fix-up loads.)
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB>
 __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<TY, TZ>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
@@ -93,7 +99,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     tile = (slot_in_seg % 8u) * per_xcd + slot_in_seg / 8u;
   }
   const int n_seg = a.x_segments > 0 ? a.x_segments : 1;
-  const int x_lo = (int)(((long)a.nx * seg) / n_seg), x_hi = (int)(((long)a.nx * (seg + 1)) / n_seg);
+  const int x_lo = a.x_begin + (int)(((long)a.x_count * seg) / n_seg), x_hi = a.x_begin + (int)(((long)a.x_count * (seg + 1)) / n_seg);
   const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
   const int t = threadIdx.x;
   const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -137,11 +143,18 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   const unsigned cell_b = (unsigned)yb * (unsigned)nz + (unsigned)zb;
   const int ctr_b = (jb + 1) * EZ + (kb + 1);  // my cell inside a grown-tile slot
 
+  // logical plane p -> the plane phase A works on: without ghost planes x is periodic; with them planes past x_hi
+  // are prefetches whose results are discarded (clamped, so that they stay inside the allocation)
   auto wrapx = [&](int p) {
-    p %= nx;
-    return p < 0 ? p + nx : p;
+    if constexpr (SLAB) {
+      return p > x_hi ? x_hi : p;
+    } else {
+      p %= nx;
+      return p < 0 ? p + nx : p;
+    }
   };
-  auto meta_load = [&](int plane, unsigned cell) -> unsigned { return a.meta[(size_t)plane * plane_cells + cell]; };
+  const ptrdiff_t pc = (ptrdiff_t)plane_cells;
+  auto meta_load = [&](int plane, unsigned cell) -> unsigned { return (a.meta + (ptrdiff_t)plane * pc)[cell]; };
 
   auto finish = [&](T(&f)[Q], bool fullway) {
     if (!fullway) {
@@ -166,14 +179,14 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) {
     mall = 0;
     if (!act_a) return;  // only the tail of the last wave is idle
-    int Xs[3];
-    Xs[0] = (x + 1 == nx) ? 0 : x + 1;
+    int Xs[3];  // storage planes of the sources (index c_x + 1 -> plane x - c_x)
+    Xs[0] = SLAB ? x + 1 : ((x + 1 == nx) ? 0 : x + 1);
     Xs[1] = x;
-    Xs[2] = (x == 0) ? nx - 1 : x - 1;
+    Xs[2] = SLAB ? x - 1 : ((x == 0) ? nx - 1 : x - 1);
     static_for<Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-      const S* row = a.src + (size_t)l * a.plane_stride + (size_t)Xs[cx + 1] * plane_cells;  // uniform
+      const S* row = a.src + (size_t)l * a.plane_stride + (ptrdiff_t)Xs[cx + 1] * pc;  // uniform
       raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
     });
     if constexpr (HASBC != 0) {
@@ -195,7 +208,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
             // asm-loaded register before the hand-placed wait would read stale data (guide section 5.7), so
             // there is no initialiser, no second writer and no select on `got`
             // (tests/test_gpu_stepper.py::test_two_step_fusion_matches_oracle guards this).
-            const S* b_opp = a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)x * plane_cells;
+            const S* b_opp = a.src + (size_t)opp<L>(l) * a.plane_stride + (ptrdiff_t)x * pc;
             S got;
 #ifdef S2_DEBUG_VISIBLE
             got = ld(b_opp, voff);
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     if (act_b) {  // wave-uniform: NB is a whole number of waves
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        S* drow = a.dst + (size_t)l * a.plane_stride + (size_t)x * plane_cells;  // uniform
+        S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
         S v[1] = {to_store<S, T>(f[l])};
         st_aligned<S, 1, true>(drow, cell_b * ES, v);
       });
@@ -354,7 +367,7 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   issue_a(wrapx(x_lo + 2), raw, fix, w_raw, mall_raw);
   lds_barrier();
   // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
-  // The last two trips prefetch planes nx + 1, nx + 2 (periodic images, discarded): 2 / nx extra work, no branch.
+  // The last two trips prefetch again plane x_hi (discarded): 2 / nx extra work, no branch.
   for (int x = x_lo; x < x_hi; ++x) {
     const int d = x - x_lo;
     unsigned wa = 0;

@@ -49,6 +49,7 @@ struct StepArgs {
   int nx, ny, nz;       // interior extent of this rank
   int halo;             // ghost planes per side (0: periodic wrap in x done here)
   int x_begin;          // first interior x plane updated by this launch
+  int x_count;          // two-step kernel only: planes updated by this launch (cut into x_segments)
   int nzq;              // nz / VEC
   CollideExtra extra;   // force vector / Smagorinsky constant (only read by the variants that use them)
   int xcd_swizzle;      // remap blockIdx so that the blocks of one row share an XCD (needs gridDim.y % 8 == 0)

@@ -70,6 +70,7 @@ int launch_typed(const StepLaunch& p) {
   a.nz = p.nz;
   a.halo = p.halo;
   a.x_begin = p.x_begin;
+  a.x_count = p.x_count;
   a.nzq = p.nz / VEC;
   a.omega = static_cast<T>(p.omega);
   a.extra.force[0] = p.force[0];

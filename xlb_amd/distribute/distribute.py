@@ -65,19 +65,29 @@ class HostStagedHalo:
     ``external_halo`` option: call ``exchange(f)`` before every step."""
 
     def __init__(self, grid, velocity_set, periodic=True):
-        self.plan = SlabPlan(grid.shape[0], grid.rank, grid.n_ranks, velocity_set._c[0], periodic=periodic)
+        self.plan = SlabPlan(grid.shape[0], grid.rank, grid.n_ranks, velocity_set._c[0], periodic=periodic, halo=grid.halo)
 
-    def exchange(self, f):
+    def exchange(self, f, depth=1):
+        """Refill f's ghost planes: depth 1 before a single step, depth 2 before a fused pair of steps."""
+        self._run(f, self.plan.messages(depth))
+
+    def exchange_masks(self, bc_mask, missing_mask=None):
+        """Ghost planes -1 and nx of the masks (the two-step kernel evaluates boundary conditions there)."""
+        self._run(bc_mask, self.plan.mask_messages())
+        if missing_mask is not None:
+            self._run(missing_mask, self.plan.mask_messages())
+
+    def _run(self, f, messages):
         import torch
 
         dist = _state["dist"]
         reqs, recvs = [], []
-        for _, pops, send_plane, ghost_plane, send_peer, recv_peer in self.plan.messages():
+        for _, pops, send_plane, ghost_plane, send_peer, recv_peer in messages:
             if send_peer is not None:
                 buf = torch.from_numpy(np.stack([f.get_plane(int(l), send_plane) for l in pops]))
                 reqs.append(dist.isend(buf, dst=send_peer))
             if recv_peer is not None:
-                rbuf = torch.from_numpy(np.empty((len(pops),) + tuple(f._s3[1:]), dtype=f.dtype))
+                rbuf = torch.from_numpy(np.empty((len(pops),) + tuple(f._s3[1:]), dtype=f.plane_dtype))
                 reqs.append(dist.irecv(rbuf, src=recv_peer))
                 recvs.append((pops, ghost_plane, rbuf))
         for r in reqs:
@@ -148,8 +158,9 @@ class SlabPlan:
     x-plane go to which neighbour, and into which ghost plane they land.  Mirrors what
     csrc/comm.cpp does; used by the CPU (gloo) protocol tests."""
 
-    def __init__(self, nx_global, rank, n_ranks, c_x, periodic=True):
-        self.rank, self.n_ranks = int(rank), int(n_ranks)
+    def __init__(self, nx_global, rank, n_ranks, c_x, periodic=True, halo=1):
+        self.rank, self.n_ranks, self.halo = int(rank), int(n_ranks), int(halo)
+        self.q = len(c_x)
         self.x_offset, self.nx_local = slab_bounds(nx_global, rank, n_ranks)
         c_x = np.asarray(c_x)
         self.right_indices = np.nonzero(c_x == 1)[0]
@@ -159,12 +170,37 @@ class SlabPlan:
         self.has_right = periodic or rank + 1 < n_ranks
         self.has_left = periodic or rank > 0
 
-    def messages(self):
-        """[(direction, populations, send storage-plane, recv ghost storage-plane, send peer, recv peer)]
-        with storage planes counted INCLUDING the left ghost (interior = 1..nx_local)."""
+    def _pair(self, tag, pops, send_plane, ghost_plane, to_right):
+        """storage planes count the left ghosts: interior plane X lives at X + halo"""
+        h = self.halo
+        if to_right:
+            return (tag, pops, send_plane + h, ghost_plane + h, self.right_rank if self.has_right else None, self.left_rank if self.has_left else None)
+        return (tag, pops, send_plane + h, ghost_plane + h, self.left_rank if self.has_left else None, self.right_rank if self.has_right else None)
+
+    def messages(self, depth=1):
+        """[(direction, populations, send storage-plane, recv ghost storage-plane, send peer, recv peer)].
+
+        depth 1 (one step): the face-crossing populations of the edge planes.  depth 2 (two fused steps, fields with
+        two ghost planes): f(t+1) is recomputed on the ghost planes -1 and nx, which takes EVERY population of the
+        neighbour's edge plane and the crossing ones of the plane behind it."""
         nx = self.nx_local
-        out = []
-        if self.has_right or self.has_left:
-            out.append(("right", self.right_indices, nx, 0, self.right_rank if self.has_right else None, self.left_rank if self.has_left else None))
-            out.append(("left", self.left_indices, 1, nx + 1, self.left_rank if self.has_left else None, self.right_rank if self.has_right else None))
-        return out
+        if depth not in (1, 2) or depth > self.halo:
+            raise ValueError(f"halo depth {depth} with {self.halo} ghost plane(s)")
+        if not (self.has_right or self.has_left):
+            return []
+        if depth == 1:
+            return [self._pair("right", self.right_indices, nx - 1, -1, True), self._pair("left", self.left_indices, 0, nx, False)]
+        every = np.arange(self.q)
+        return [
+            self._pair("right", every, nx - 1, -1, True),
+            self._pair("right2", self.right_indices, nx - 2, -2, True),
+            self._pair("left", every, 0, nx, False),
+            self._pair("left2", self.left_indices, 1, nx + 1, False),
+        ]
+
+    def mask_messages(self):
+        """Ghost planes -1 and nx of a per-cell mask (one device plane)."""
+        nx = self.nx_local
+        if not (self.has_right or self.has_left):
+            return []
+        return [self._pair("right", np.arange(1), nx - 1, -1, True), self._pair("left", np.arange(1), 0, nx, False)]

@@ -6,7 +6,8 @@
 Slab decomposition (one process per GPU): when the process context has ``n_ranks > 1`` (see
 ``xlb_amd.distribute``) or ``backend_config={"halo": True}`` is given, ``shape`` is the GLOBAL
 domain, this rank owns the x-planes ``[x_offset, x_offset + local_shape[0])`` and fields carry
-one ghost plane per side.
+ghost planes: TWO per side by default (the two-steps-per-pass kernel recomputes f(t+1) on the inner
+one), ``backend_config={"halo": 1}`` for the minimum a single step needs.
 """
 
 from .. import _lib
@@ -33,7 +34,13 @@ class HipGrid(Grid):
         rank = self.backend_config.get("rank", self.context.rank)
         n_ranks = self.backend_config.get("n_ranks", self.context.n_ranks)
         self.rank, self.n_ranks = int(rank), int(n_ranks)
-        self.halo = 1 if (self.n_ranks > 1 or self.backend_config.get("halo", False)) else 0
+        want = self.backend_config.get("halo", None)
+        if want is None or want is False:
+            self.halo = 2 if self.n_ranks > 1 else 0
+        else:
+            self.halo = 2 if want is True else int(want)
+        if self.halo not in (0, 1, 2) or (self.n_ranks > 1 and self.halo == 0):
+            raise ValueError(f"halo={want!r}: slab-decomposed fields need 1 or 2 ghost planes")
         if self.halo and self.dim != 3:
             raise ValueError("slab decomposition needs a 3-D grid")
         if self.n_ranks > 1:

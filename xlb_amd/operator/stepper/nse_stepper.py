@@ -103,13 +103,40 @@ class IncompressibleNavierStokesStepper(Stepper):
 
     def run(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """``n_steps`` x (step, swap) in native code; returns (f_current, f_other)."""
+        if f_0.halo > 0 and self._ctx.get_option("external_halo"):
+            return self._run_host_staged(f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep)
         self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
         return (f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)
 
     def run_timed(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """As :meth:`run`; also returns the device time in ms measured with HIP events."""
+        if f_0.halo > 0 and self._ctx.get_option("external_halo"):
+            raise NotImplementedError("run_timed measures the native loop; the host-staged halo transport has none")
         ms = self._native_stepper().run_timed(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
         return ((f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)), ms
+
+    def _run_host_staged(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep):
+        """The native run loop with the ghost planes moved by the host (``init_process_group(transport="host")``):
+        same kernels and the same pairing of steps as ``xlbhip_run``, the debugging transport in between."""
+        from ...distribute import HostStagedHalo
+
+        native = self._native_stepper()
+        halo = HostStagedHalo(self.grid, self.velocity_set)
+        cur, oth, i = f_0, f_1, 0
+        fuse = f_0.halo >= 2 and n_steps >= 2 and native.step2_eligible(cur, oth, bc_mask, missing_mask)
+        if fuse and bc_mask is not None and self.boundary_conditions:
+            halo.exchange_masks(bc_mask, missing_mask)
+        while i < n_steps:
+            if fuse and n_steps - i >= 2:
+                halo.exchange(cur, depth=2)
+                native.step2(cur, oth, bc_mask, missing_mask, omega, first_timestep + i)
+                i += 2
+            else:
+                halo.exchange(cur, depth=1)
+                native.step(cur, oth, bc_mask, missing_mask, omega, first_timestep + i)
+                i += 1
+            cur, oth = oth, cur
+        return cur, oth
 
     @property
     def has_post_streaming_bc(self):
