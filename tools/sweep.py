@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--variant", action="append", default=[])
+    ap.add_argument("--halo", type=int, default=0, help="ghost planes per side (the multi-rank field layout on one rank: ring exchange onto itself)")
+    ap.add_argument("--self-comm", action="store_true", help="with --halo: a real one-rank RCCL communicator instead of device copies")
     ap.add_argument("--realloc", action="store_true", help="variants change the field layout (plane_pad_bytes): rebuild fields per variant")
     args = ap.parse_args()
 
@@ -42,9 +44,13 @@ def main():
     ctx = get_context()
     defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap", "xcd_swizzle", "nt_load", "fuse2", "fuse2_xcd", "fuse2_lpt", "fuse2_xseg")}
     n = args.size
+    if args.self_comm:
+        from xlb_amd import _lib
+
+        ctx.comm_init(0, 1, _lib.comm_unique_id())
 
     def setup():
-        grid = grid_factory((n, n, n))
+        grid = grid_factory((n, n, n), backend_config={"halo": args.halo} if args.halo else None)
         if args.workload == "periodic":
             bcs = []
         elif args.workload == "one_cell":
@@ -91,7 +97,8 @@ def main():
                     fld.free()
     cells = float(n) ** 3
     b_alg = 2 * vs.q * pp.store_precision.np_dtype(0).itemsize
-    print(f"# {args.lattice} {args.collision} {args.policy} {args.workload} {n}^3, {args.steps} steps x {args.rounds} rounds")
+    print(f"# {args.lattice} {args.collision} {args.policy} {args.workload} {n}^3, {args.steps} steps x {args.rounds} rounds, halo {args.halo}"
+          f"{' (RCCL self communicator)' if args.self_comm else ''}")
     print(f"{'variant':44s} {'med ms':>8s} {'min ms':>8s} {'MLUPS(med)':>11s} {'GB/s':>8s} {'frac':>6s}")
     for v in variants:
         t = np.array(times[v])
