@@ -408,6 +408,91 @@ __device__ __forceinline__ void smagorinsky(T (&f)[L::Q], const T (&feq)[L::Q], 
 }
 
 // COLL: bits 0-1 = XLBHIP_BGK / XLBHIP_KBC / XLBHIP_SMAGORINSKY_LES_BGK, bit 2 = exact-difference forcing
+// fp32 BGK with the population pairs (l, opp l) evaluated by PACKED fp32 instructions (v_pk_add_f32 /
+// v_pk_mul_f32: two IEEE-rounded results per lane per issue).  On MI355X a packed instruction costs the SIMD as much
+// as its two scalar halves (the guide's "anti-lever" beside MFMAs), so this does not raise the VALU peak; what it buys
+// the two-step kernel — 300 VALU instructions per cell update, 2 waves per SIMD in phase B, each able to issue only
+// every 4th cycle — is fewer ISSUE slots: measured -3...-5 % (A/B on one box, tools/ab_libs.sh), with hipcc's own
+// SLP packing of the scalar code switched off for that file (it scrambled the moment sums: +2 %).  Every population still sees exactly the
+// operations of feq_dir + bgk in the same order — c_opp = -c, so the pair's operands are {u_a, -u_a} (x - y == x + (-y)
+// in IEEE arithmetic), w and rho*w are shared — hence bit-identical results; tests compare against the oracle.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// k-th population l (in index order) with l < opp(l)
+template <class L>
+constexpr int pair_first(int k) {
+  int n = 0;
+  for (int l = 0; l < L::Q; ++l)
+    if (l < opp<L>(l)) {
+      if (n == k) return l;
+      ++n;
+    }
+  return -1;
+}
+template <class L, int GMAX>
+__device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, const float (&u)[3], float omega) {
+  const float usqr = usqr_of<L, float>(u);
+  f32x2 U[3];
+  static_for<3>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    U[a] = f32x2{u[a], -u[a]};
+  });
+  const f32x2 usq2 = {usqr, usqr}, om2 = {omega, omega};
+  const f32x2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f}, three = {3.0f, 3.0f};
+  // the rest population(s): scalar
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l == opp<L>(l)) {
+      const float fneq = f[l] - feq_dir<L, float, l>(rho, u, usqr);
+      f[l] = f[l] - omega * fneq;
+    }
+  });
+  // the (Q - 1) / 2 pairs, GMAX at a time and stage by stage: a packed result needs a wait state before its consumer
+  // (hipcc fills it with s_nop when the next instruction depends on it), so the chains of a group are interleaved
+  // (measured best: 3 for the boundary-condition variant of the two-step kernel, 1 for the plain one)
+  constexpr int NP = (L::Q - 1) / 2;
+  static_for<(NP + GMAX - 1) / GMAX>([&](auto gc) {
+    constexpr int g0 = decltype(gc)::value * GMAX;
+    constexpr int G = (g0 + GMAX <= NP) ? GMAX : NP - g0;  // the last group may be short (D2Q9: 4 pairs, D3Q27: 13)
+    f32x2 cu[G], t[G], p[G];
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
+      f32x2 dot = {0.0f, 0.0f};
+      static_for<3>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        constexpr int cl = L::c(a, l);
+        if constexpr (a >= 3 - L::D) {
+          if constexpr (cl == 1) dot = dot + U[a];
+          if constexpr (cl == -1) dot = dot - U[a];
+        }
+      });
+      cu[k] = dot;
+    });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; cu[k] = three * cu[k]; });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = half * cu[k]; });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = one + t[k]; });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = cu[k] * t[k]; });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = one + t[k]; });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = t[k] - usq2; });
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
+      const float rw = rho * float(L::w(l));
+      t[k] = f32x2{rw, rw} * t[k];  // feq of the pair
+    });
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
+      p[k] = f32x2{f[l], f[opp<L>(l)]};
+      t[k] = p[k] - t[k];  // fneq
+    });
+    static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = om2 * t[k]; });
+    static_for<G>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
+      p[k] = p[k] - t[k];
+      f[l] = p[k].x;
+      f[opp<L>(l)] = p[k].y;
+    });
+  });
+}
+
 constexpr int COLL_FORCED = 4;
 
 struct CollideExtra {
@@ -457,6 +542,15 @@ __device__ __forceinline__ void collide(T (&f)[L::Q], T omega, const CollideExtr
       });
     }
   }
+}
+
+// moments + packed-pair BGK: what the VALU-bound two-step kernel calls (the single-step kernel is HBM-bound and was
+// measured 4 % slower with it: it stays on collide<>)
+template <class L, int GMAX>
+__device__ __forceinline__ void collide_bgk_packed(float (&f)[L::Q], float omega) {
+  float rho, u[3];
+  moments<L, float>(f, rho, u);
+  bgk_packed_pairs<L, GMAX>(f, rho, u, omega);
 }
 
 }  // namespace xlb

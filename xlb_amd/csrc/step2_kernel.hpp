@@ -44,18 +44,17 @@ __device__ __forceinline__ unsigned meta_kind(unsigned w) { return w & 0xfu; }
 __device__ __forceinline__ unsigned meta_slot(unsigned w) { return (w >> 4) & 0xfu; }
 
 // Union over the wave of the missing bits of its halfway-wall lanes, as a UNIFORM (scalar) word: 0 for a fluid
-// wave; for a z-face wave 5 of 19 bits.  Every per-population boundary loop below tests it with scalar branches,
-// so a boundary wave pays for the populations it really redirects and one ballot pass per plane, not for 19
-// vector tests in four places (measured: hull tiles cost 1.7x a fluid tile before this).
-template <int Q>
-__device__ __forceinline__ unsigned wave_missing_union(bool hw, unsigned m) {
-  unsigned all = 0;
-  if (__builtin_amdgcn_ballot_w64(hw) != 0ull) {
-#pragma unroll
-    for (int l = 0; l < Q; ++l)
-      if (__builtin_amdgcn_ballot_w64(hw && ((m >> l) & 1u)) != 0ull) all |= 1u << l;
-  }
-  return all;
+// wave; for a z-face wave 5 of 19 bits.  One scalar test of it separates fluid waves (straight-line code) from
+// boundary waves, whose per-population work is branch-free selects.  OR-reduction by DPP row shifts (lane 15 of
+// every row ends up with its row's union) + 4 readlanes: 11 instructions.  Must be called with ALL lanes active
+// (v_readlane ignores EXEC: an inactive lane 15/31/47/63 would deliver a stale register): idle lanes pass m = 0.
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 15) | (unsigned)__builtin_amdgcn_readlane((int)v, 31) |
+         (unsigned)__builtin_amdgcn_readlane((int)v, 47) | (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // slot (0..7) of a bc id in the packed kernel arguments; ids beyond the first 8 make the stepper ineligible
@@ -158,7 +157,10 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
 
   auto finish = [&](T(&f)[Q], bool fullway) {
     if (!fullway) {
-      collide<L, T, COLL>(f, a.omega, a.extra);
+      if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4)
+        collide_bgk_packed<L, (HASBC != 0 ? 3 : 1)>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp)
+      else
+        collide<L, T, COLL>(f, a.omega, a.extra);
     } else {
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
@@ -178,6 +180,10 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
   auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) {
     mall = 0;
+    if constexpr (HASBC != 0) {
+      const unsigned kind_ = meta_kind(w);
+      mall = wave_or((act_a && (kind_ == K_HW || kind_ == K_HW_MOVING)) ? (w >> 8) : 0u);  // all lanes active here
+    }
     if (!act_a) return;  // only the tail of the last wave is idle
     int Xs[3];  // storage planes of the sources (index c_x + 1 -> plane x - c_x)
     Xs[0] = SLAB ? x + 1 : ((x + 1 == nx) ? 0 : x + 1);
@@ -196,7 +202,6 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       // steady-state loop exact (see the note above).  finish_a waits for them by hand.
       const unsigned kind = meta_kind(w), m = w >> 8;
       const bool hw = kind == K_HW || kind == K_HW_MOVING;
-      mall = wave_missing_union<Q>(hw, m);
       if (mall != 0u) {
         const unsigned voff = cell_a * ES;
         static_for<Q>([&](auto lc) {
@@ -224,31 +229,35 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       }
     }
   };
-  // boundary treatment on registers: f holds the (redirected) pulls
-  auto bc_regs = [&](T(&f)[Q], unsigned w, unsigned mall, bool& fullway) {
-    const unsigned kind = meta_kind(w), m = w >> 8;
-    const unsigned vbase = meta_slot(w) * 32u;
-    // (each branch reads the table through its own opaque index: identical LDS reads in two branches would be
-    // hoisted above them and stay live in the fluid path)
+  // boundary kinds that replace whole cells (halfway walls are handled where the pulls are redirected)
+  auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) {
+    const unsigned kind = meta_kind(w);
     if (kind == K_EQ) {
-      const T* val = bcval + opaque(vbase);
+      const T* val = bcval + opaque(meta_slot(w) * 32u);
       static_for<Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
-    } else if (kind == K_HW) {
-      // no-slip wall: f[l] already is f_pre[opp l]; the reference still adds its 0.0 moving-wall term
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        if (((mall >> l) & 1u) == 0u) return;  // scalar
-        if ((m >> l) & 1u) f[l] = f[l] + T(0);
-      });
-    } else if (kind == K_HW_MOVING) {
-      const T* val = bcval + opaque(vbase);
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        if (((mall >> l) & 1u) == 0u) return;  // scalar
-        if ((m >> l) & 1u) f[l] = f[l] + val[l];
-      });
     } else if (kind == K_FW) {
       fullway = true;
+    }
+  };
+  // halfway wall, population l of a lane whose missing bit is set: the redirected pull `got` (own cell, opposite
+  // population) + the moving-wall term; the reference adds its 0.0 term for no-slip walls too (bc_halfway_bounce_back.py:116-134).
+  // Branch-free over the wave: BRANCHES, not arithmetic, made boundary waves slow (z-face tiles cost 2.25x a fluid tile
+  // with per-population scalar branches in four places).  any_moving is wave-uniform.
+  auto hw_apply = [&](T(&f)[Q], const T(&got)[Q], unsigned mm, unsigned w, bool any_moving) {
+    if (!any_moving) {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        const T cand = got[l] + T(0);
+        f[l] = ((mm >> l) & 1u) ? cand : f[l];
+      });
+    } else {
+      const T* val = bcval + meta_slot(w) * 32u;
+      const bool mov = meta_kind(w) == K_HW_MOVING;
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        const T cand = got[l] + (mov ? val[l] : T(0));
+        f[l] = ((mm >> l) & 1u) ? cand : f[l];
+      });
     }
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
@@ -256,38 +265,34 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
-    if constexpr (HASBC != 0) {
-      const unsigned kind = meta_kind(w), m = w >> 8;
-      {
-        const bool hw = kind == K_HW || kind == K_HW_MOVING;
-        if (hw) {
-          // The fix-up loads are invisible to the compiler: wait for them here (boundary lanes' waves only).
-          // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
-          // stores of the phase B that just ran (waves that own output cells) and possibly the meta prefetch,
-          // so vmcnt(Q) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
-          // which made hull tiles 3x slower than fluid tiles).  Extra younger operations only make this safer.
-          static_assert(Q == 19, "vmcnt immediate below assumes 19 stores per phase-B thread");
-          // (in the prologue no phase B has run yet: nothing younger, so drain everything)
-          if (steady && __builtin_amdgcn_readfirstlane(t) < G::NB)
-            asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-          else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<Q>([&](auto lc) {
-            constexpr int l = decltype(lc)::value;
-            if (((mall >> l) & 1u) == 0u) return;  // scalar
-            if ((m >> l) & 1u) {
-              S v = fix[l];
-              asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
-              f[l] = to_compute<T, S>(v);
-            }
-          });
-        }
-      }
-    }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (meta_kind(w) != 0u) bc_regs(f, w, mall, fullway);
+      const unsigned kind = meta_kind(w);
+      const bool hw = kind == K_HW || kind == K_HW_MOVING;
+      if (mall != 0u) {  // wave-uniform: some lane of this wave has redirected pulls
+        // The fix-up loads are invisible to the compiler: wait for them here (boundary waves only).
+        // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
+        // stores of the phase B that just ran (waves that own output cells) and possibly the meta prefetch,
+        // so vmcnt(Q) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
+        // which made hull tiles 3x slower than fluid tiles).  Extra younger operations only make this safer.
+        static_assert(Q == 19, "vmcnt immediate below assumes 19 stores per phase-B thread");
+        // (in the prologue no phase B has run yet: nothing younger, so drain everything)
+        if (steady && __builtin_amdgcn_readfirstlane(t) < G::NB)
+          asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned mm = hw ? (w >> 8) : 0u;
+        T got[Q];
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          S v = fix[l];  // (populations outside `mall` were never loaded: garbage that no lane selects)
+          asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
+          got[l] = to_compute<T, S>(v);
+        });
+        hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(kind == K_HW_MOVING) != 0ull);
+      }
+      if (kind != 0u) bc_regs(f, w, fullway);
     }
     finish(f, fullway);
     if (act_a) {
@@ -301,22 +306,18 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   };
 
   // phase B: f(t+2) on plane x from the LDS slots of planes x-1, x, x+1 -> global (19 unconditional stores)
-  auto phase_b = [&](int x, int slot_m, int slot_0, int slot_p) {
-    if (!act_b) return;  // whole waves (NB % 64 == 0)
+  auto phase_b_compute = [&](T(&f)[Q], int slot_m, int slot_0, int slot_p) {
     const T* base[3];  // index c_x + 1 -> plane x - c_x
     base[0] = lds + slot_p * (Q * NE);
     base[1] = lds + slot_0 * (Q * NE);
     base[2] = lds + slot_m * (Q * NE);
     unsigned w = 0;
     if constexpr (HASBC != 0) w = ldsmeta[slot_0 * NE + ctr_b];
-    const unsigned m = w >> 8;
-    T f[Q];
-    unsigned mall = 0;
-    bool hw = false;
+    unsigned mall = 0, mm = 0;
     if constexpr (HASBC != 0) {
       const unsigned kind = meta_kind(w);
-      hw = kind == K_HW || kind == K_HW_MOVING;
-      mall = wave_missing_union<Q>(hw, m);  // uniform: populations some lane of this wave reads from its own cell
+      mm = (kind == K_HW || kind == K_HW_MOVING) ? (w >> 8) : 0u;
+      mall = wave_or(mm);  // uniform; all lanes of the wave are active here (NB is a whole number of waves)
     }
     if (mall == 0u) {  // fluid wave (or only fullway / equilibrium lanes): one scalar branch, then straight-line reads
       static_for<Q>([&](auto lc) {
@@ -325,31 +326,39 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
         f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
       });
     } else {
+      // boundary wave: a lane whose missing bit l is set reads its own cell's opposite population instead (select on
+      // the LDS index, no branch), then the halfway-wall terms are applied to exactly those populations
+      T got[Q];
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        if (((mall >> l) & 1u) == 0u) {  // scalar
-          f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
-        } else {
-          int idx = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
-          if (hw && ((m >> l) & 1u)) idx = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;  // own cell, opposite population
-          f[l] = lds[idx];
-        }
+        const int idx_pull = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
+        const int idx_own = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;
+        got[l] = lds[((mm >> l) & 1u) ? idx_own : idx_pull];
+        f[l] = got[l];
       });
+      hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(meta_kind(w) == K_HW_MOVING) != 0ull);
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (meta_kind(w) != 0u) bc_regs(f, w, mall, fullway);
+      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
     }
     finish(f, fullway);
-    if (act_b) {  // wave-uniform: NB is a whole number of waves
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
-        S v[1] = {to_store<S, T>(f[l])};
-        st_aligned<S, 1, true>(drow, cell_b * ES, v);
-      });
-    }
+  };
+  // Tried and rejected: issuing the 19 stores from EVERY wave outside the branch (buffer stores, idle waves aimed past
+  // the end of the buffer) makes hipcc's vmcnt model exact — with the stores inside `if (act_b)` it waits for the
+  // prefetched pulls with vmcnt(19)...vmcnt(1), i.e. drains the wave's own stores every plane — but ran 9 % SLOWER
+  // without boundary conditions and the same with them: the kernel is bound by VALU issue, not by these waits.
+  auto phase_b = [&](int x, int slot_m, int slot_0, int slot_p) {
+    if (!act_b) return;  // whole waves (NB % 64 == 0)
+    T f[Q];
+    phase_b_compute(f, slot_m, slot_0, slot_p);
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
+      S v[1] = {to_store<S, T>(f[l])};
+      st_aligned<S, 1, true>(drow, cell_b * ES, v);
+    });
   };
 
   // Plane p lives in slot (p + 1) % 3 (p = -1 is the periodic image nx - 1).
