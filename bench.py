@@ -194,15 +194,9 @@ def main():
     achieved = b_alg * float(n) ** 3 / (step_ms * 1e-3) / 1e9  # per GPU, GB/s
     if rank != 0:
         return
-    # xlbhip_run fuses two steps per launch where eligible (D3Q19 BGK fp32, basic BCs, ny % 8 == nz % 64 == 0,
-    # enough tile segments to fill the chip): mirror the library's rule to name the kernel that actually ran
-    items = (n // 8) * (n // 64) * (4 if n >= 128 else (2 if n >= 64 else 1))
-    rounds = -(-items // 256)
-    fused2 = (ctx.get_option("fuse2") >= 1 and args.lattice == "D3Q19" and args.collision == "BGK" and args.policy == "FP32FP32"
-              and n % 64 == 0 and args.steps >= 2 and items * 100 >= rounds * 256 * 85)
-    if fused2 and args.workload == "cavity_halfway":
-        tys, tzs = n // 8, n // 64
-        fused2 = (tys * tzs - max(tys - 2, 0) * max(tzs - 2, 0)) * 100 <= tys * tzs * 40
+    # xlbhip_run fuses two steps per launch where the library's rule says so (D3Q19 BGK fp32, basic BCs,
+    # ny % 8 == nz % 64 == 0, enough tile segments to fill the chip): ask it, to name the kernel that actually ran
+    fused2 = args.steps >= 4 and stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
     kernel = (f"k_step2<{args.lattice}, {args.collision}, {args.policy}> (two steps per launch through LDS)" if fused2 else
               f"k_step<{args.lattice}, {args.collision}, {args.policy}, vec{ctx.get_option('vec') or 1}>")
     out = {

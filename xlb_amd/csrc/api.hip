@@ -658,13 +658,30 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   return p;
 }
 
-// x segments per tile column of the two-step kernel: finer work items balance the expensive hull tiles of
-// wall-bounded domains (measured at 512^3: 4-8 segments best; each costs 3 warm-up planes)
+// x segments per tile column of the two-step kernel.  One block per CU marches a segment, so the launch runs in
+// ceil(tiles * n / CUs) rounds of (planes per segment + 3 warm-up planes): pick the n that minimises that product
+// (320^3: 4 -> 8 segments = 3.1 -> 6.25 rounds, -9 %; 256^3: 2 segments = exactly one round).  With halfway walls the
+// hull tiles are the expensive ones and finer items balance them better: take the most segments of >= 32 planes
+// (measured at 256^3 ... 512^3: profiles/r01/sweeps.md).
 static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
   const int64_t xseg = opt(s->ctx, "fuse2_xseg", 0);
-  int n = xseg > 0 ? (int)xseg : 4;
-  while (n > 1 && p.x_count / n < 32) n /= 2;
-  return n;
+  if (xseg > 0) {
+    int n = (int)xseg;
+    while (n > 1 && p.x_count / n < 8) n /= 2;
+    return n;
+  }
+  const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
+  int best = 1;
+  long best_cost = -1;
+  for (int n = 1; n <= 8; n *= 2) {
+    if (n > 1 && p.x_count / n < 32) break;
+    const long cost = ((tiles * n + cus - 1) / cus) * (p.x_count / n + 3);
+    if (best_cost < 0 || cost < best_cost || s->needs_missing) {
+      best = n;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
 // two steps in one pass (a -> scratch-free: src -> dst holds f(t+2)); caller checked eligibility
@@ -716,12 +733,12 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     const long items = (long)(p.ny / 8) * (p.nz / 64) * fuse2_segments(s, p), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
     const long rounds = (items + cus - 1) / cus;
     if (items * 100 < rounds * cus * 85) return false;
-    // halfway walls make the hull tiles ~1.7x as expensive as fluid tiles; with too many of them (256^3: 53 %)
-    // two single steps are faster (measured: 31.5 vs 37.0 GLUPS), at 384^3 (36 %) and 512^3 (27 %) fusing wins
+    // halfway walls make the hull tiles ~1.5x as expensive as fluid tiles; when most tiles are hull tiles two single
+    // steps are faster (256^3, 53 % hull tiles: fused 41.7 vs 38.2 GLUPS; thinner domains lose)
     if (s->needs_missing) {
       const long tys = p.ny / 8, tzs = p.nz / 64;
       const long hull = tys * tzs - (tys > 2 ? tys - 2 : 0) * (tzs > 2 ? tzs - 2 : 0);
-      if (hull * 100 > tys * tzs * 40) return false;
+      if (hull * 100 > tys * tzs * 60) return false;
     }
   }
   return true;
