@@ -66,7 +66,13 @@ enum {
   XLBHIP_BC_ZOUHE_VELOCITY = 5,        /* bc_zouhe.py:218-304, values[0..2] = velocity (3-component internal form) */
   XLBHIP_BC_ZOUHE_PRESSURE = 6,        /* values[0] = density */
   XLBHIP_BC_REGULARIZED_VELOCITY = 7,  /* bc_regularized.py:78-137 */
-  XLBHIP_BC_REGULARIZED_PRESSURE = 8
+  XLBHIP_BC_REGULARIZED_PRESSURE = 8,
+  /* ExtrapolationOutflowBC, JAX branch (bc_extrapolation_outflow.py:98-145): streaming step = the missing populations
+   * take the cell's own opposite PRE-stream population; after the collision the outgoing populations are overwritten
+   * with cs * f_post_stream(neighbour behind the face) + (1 - cs) * f_post_stream(cell) ("auxiliary data", read back by
+   * the next step).  values[0..2] = outward face normal (internal 3-component form), values[3] = cs = 1/sqrt(3) and
+   * values[4] = 1 - cs, both rounded in the compute dtype by the host side. */
+  XLBHIP_BC_EXTRAPOLATION_OUTFLOW = 9
 };
 
 /* One boundary condition as the stepper sees it.  `values` holds, in COMPUTE

@@ -39,6 +39,7 @@ KIND_EQUILIBRIUM = "equilibrium"
 KIND_HALFWAY_BB = "halfway_bounce_back"
 KIND_FULLWAY_BB = "fullway_bounce_back"
 KIND_DO_NOTHING = "do_nothing"
+KIND_EXTRAPOLATION_OUTFLOW = "extrapolation_outflow"
 # SURVEY.md section 8f rank 1 ("next"): inlet / outlet family with constant prescribed values
 KIND_ZOUHE_VELOCITY = "zouhe_velocity"
 KIND_ZOUHE_PRESSURE = "zouhe_pressure"
@@ -334,6 +335,38 @@ def exact_difference_force(f_post, feq, lat, force_vector):
 # ----------------------------------------------------------------------------
 # Boundary conditions
 # ----------------------------------------------------------------------------
+def outflow_normal(indices):
+    """bc_extrapolation_outflow.py:78-92 (_get_normal_vectors)."""
+    from collections import Counter
+
+    freq = [Counter(int(v) for v in coord).most_common(1)[0] for coord in indices]
+    counts = np.array([c for _, c in freq])
+    elements = np.array([e for e, _ in freq])
+    normal = counts // counts.max()
+    if elements[np.argmax(counts)] == 0:
+        normal = normal * -1
+    return normal
+
+
+def assemble_auxiliary_data(bc, f_pre, f_post, bc_mask, missing_mask, lat):
+    """ExtrapolationOutflowBC.assemble_auxiliary_data, bc_extrapolation_outflow.py:104-134 (JAX); every other BC
+    returns f_post unchanged (boundary_condition.py:138-144).  f_pre = post-stream, f_post = post-collision."""
+    if bc.kind != KIND_EXTRAPOLATION_OUTFLOW:
+        return f_post
+    T = f_post.dtype.type
+    axes = tuple(range(1, lat.d + 1))
+    normal = tuple(int(v) for v in bc.normal)
+    sound_speed = T(1.0) / np.sqrt(T(3.0))
+    boundary = _bcast(bc_mask == bc.id, lat.q)
+    neighbour = np.roll(boundary, tuple(-v for v in normal), axis=axes)
+    fpop = np.where(boundary, f_pre, f_post)
+    fpop_neighbour = np.where(neighbour, f_pre, f_post)
+    fpop_neighbour = np.roll(fpop_neighbour, normal, axis=axes)
+    fpop_extrapolated = sound_speed * fpop_neighbour + (T(1.0) - sound_speed) * fpop
+    known_mask = missing_mask.astype(bool)[lat.opp]
+    return np.where(np.logical_and(boundary, known_mask), fpop_extrapolated[lat.opp], f_post)
+
+
 class BC:
     """Plain descriptor of an in-scope boundary condition.
 
@@ -352,6 +385,7 @@ class BC:
         self.step = STEP_COLLISION if kind == KIND_FULLWAY_BB else STEP_STREAMING
         # bc_halfway_bounce_back.py:60 sets needs_padding; others keep the base False
         self.needs_padding = kind == KIND_HALFWAY_BB or kind in ZOUHE_KINDS  # bc_zouhe.py:146
+        self.normal = outflow_normal(self.indices) if kind == KIND_EXTRAPOLATION_OUTFLOW else None
 
     def pad_indices(self, lat):
         """boundary_condition.py:123-136"""
@@ -390,6 +424,10 @@ def apply_bc(bc, f_pre, f_post, bc_mask, missing_mask, lat, policy):
             mw = comp.reshape((lat.q,) + (1,) * lat.d)
         cond = np.logical_and(missing_mask.astype(bool), _bcast(boundary, lat.q))
         return np.where(cond, f_pre[lat.opp] + mw, f_post)
+    if bc.kind == KIND_EXTRAPOLATION_OUTFLOW:
+        # bc_extrapolation_outflow.py:137-145
+        cond = np.logical_and(missing_mask.astype(bool), _bcast(boundary, lat.q))
+        return np.where(cond, f_pre[lat.opp], f_post)
     if bc.kind == KIND_FULLWAY_BB:
         return np.where(_bcast(boundary, lat.q), f_pre[lat.opp], f_post)
     if bc.kind == KIND_DO_NOTHING:
@@ -518,6 +556,7 @@ def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collisi
     if force_vector is not None:
         post_coll = exact_difference_force(post_coll, feq, lat, force_vector)
     for bc in bcs:
+        post_coll = assemble_auxiliary_data(bc, post_stream, post_coll, bc_mask, missing_mask, lat)  # nse_stepper.py:270-272
         if bc.step == STEP_COLLISION:
             post_coll = apply_bc(bc, post_stream, post_coll, bc_mask, missing_mask, lat, policy)
     return post_coll.astype(S)

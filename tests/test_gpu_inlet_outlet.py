@@ -95,3 +95,90 @@ def test_argument_validation():
         ZouHeBC("pressure", prescribed_value=(1.0, 0.0, 0.0), indices=[[0], [0], [0]])
     with pytest.raises(NotImplementedError):
         RegularizedBC("velocity", profile=lambda: None, indices=[[0], [0], [0]])
+
+
+# ---- ExtrapolationOutflowBC (bc_extrapolation_outflow.py, JAX semantics) --------------------------------------
+from xlb_amd.operator.boundary_condition import ExtrapolationOutflowBC, FullwayBounceBackBC  # noqa: E402
+
+OUTFLOW_CASES = [("D2Q9", (24, 12), "FP32FP32", "BGK"), ("D3Q19", (16, 8, 12), "FP32FP32", "BGK"), ("D3Q27", (10, 6, 8), "FP32FP32", "KBC"),
+                 ("D3Q19", (8, 6, 8), "FP64FP64", "BGK"), ("D3Q19", (12, 6, 8), "FP32FP16", "BGK")]
+
+
+def outflow_channel(lattice, shape, policy, walls_cls, inlet_face, outlet_face):
+    """velocity inlet on one face, extrapolation outflow on the opposite one, walls on the other faces"""
+    vs, pp = init_hip(lattice, policy)
+    lat = orc.Lattice(lattice)
+    d = lat.d
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    all_faces = ["left", "right", "bottom", "top"] + (["front", "back"] if d == 3 else [])
+    faces = [f for f in all_faces if f not in (inlet_face, outlet_face)]
+    walls = [sum((box[f][i] for f in faces), []) for i in range(d)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    axis = {"left": 0, "right": 0, "front": 1, "back": 1, "bottom": d - 1, "top": d - 1}[inlet_face]
+    sign = 1.0 if inlet_face in ("left", "front", "bottom") else -1.0
+    u_in = tuple(sign * 0.03 if a == axis else 0.0 for a in range(d))
+    b_w = walls_cls(indices=walls)
+    b_in = RegularizedBC("velocity", prescribed_value=u_in, indices=box_ne[inlet_face])
+    b_out = ExtrapolationOutflowBC(indices=box_ne[outlet_face])
+    wkind = orc.KIND_FULLWAY_BB if walls_cls is FullwayBounceBackBC else orc.KIND_HALFWAY_BB
+    obcs = [orc.BC(wkind, b_w.id, walls), orc.BC(orc.KIND_REGULARIZED_VELOCITY, b_in.id, box_ne[inlet_face], prescribed=u_in),
+            orc.BC(orc.KIND_EXTRAPOLATION_OUTFLOW, b_out.id, box_ne[outlet_face])]
+    assert np.array_equal(b_out.normal, obcs[2].normal)
+    return grid, [b_w, b_in, b_out], lat, obcs
+
+
+@pytest.mark.parametrize("walls_cls", [FullwayBounceBackBC, HalfwayBounceBackBC])
+@pytest.mark.parametrize("lattice,shape,policy,collision", OUTFLOW_CASES)
+def test_extrapolation_outflow_vs_oracle(lattice, shape, policy, collision, walls_cls):
+    """The order [walls, inlet, outlet] of examples/cfd/flow_past_sphere_3d.py:108-112.  Bit-exact against the oracle:
+    the streaming part lives in the step kernel, the auxiliary data in k_outflow_aux (both per-cell code, the
+    oracle is roll-based like the reference).  No reference test pins this BC."""
+    grid, bcs, lat, obcs = outflow_channel(lattice, shape, policy, walls_cls, "left", "right")
+    assert bcs[2].normal.tolist() == [1] + [0] * (lat.d - 1)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs, collision_type=collision)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    f_np = orc.perturbed_init(shape, lat, policy, seed=41)
+    f_0.assign(f_np)
+    for steps in (1, 24):
+        f_0.assign(f_np)
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.4, steps)
+        with np.errstate(all="ignore"):
+            exp = orc.run(f_np, o_bm, o_mm, obcs, 1.4, lat, steps, policy, collision)
+        out = a.numpy()
+        assert np.array_equal(out, exp), f"{steps} steps: max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out.astype(np.float64) - exp).max()}"
+        f_0, f_1 = (a, b) if a is f_0 else (b, a)
+
+
+@pytest.mark.parametrize("inlet_face,outlet_face,normal", [("right", "left", [-1, 0, 0]), ("bottom", "top", [0, 0, 1]), ("back", "front", [0, -1, 0])])
+def test_extrapolation_outflow_other_faces(inlet_face, outlet_face, normal):
+    grid, bcs, lat, obcs = outflow_channel("D3Q19", (10, 8, 12), "FP32FP32", HalfwayBounceBackBC, inlet_face, outlet_face)
+    assert bcs[2].normal.tolist() == normal
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.build_masks((10, 8, 12), lat, obcs)
+    f_np = orc.perturbed_init((10, 8, 12), lat, seed=43)
+    f_0.assign(f_np)
+    a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.7, 15)
+    exp = orc.run(f_np, o_bm, o_mm, obcs, 1.7, lat, 15)
+    assert np.array_equal(a.numpy(), exp)
+
+
+def test_extrapolation_outflow_operator_call():
+    """bc(f_pre, f_post, bc_mask, missing_mask): the streaming-step form (bc_extrapolation_outflow.py:137-145)."""
+    grid, bcs, lat, obcs = outflow_channel("D3Q19", (8, 6, 8), "FP32FP32", HalfwayBounceBackBC, "left", "right")
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    rng = np.random.default_rng(3)
+    pre = rng.random((19, 8, 6, 8)).astype(np.float32)
+    post = rng.random((19, 8, 6, 8)).astype(np.float32)
+    f_0.assign(pre)
+    f_1.assign(post)
+    out = bcs[2](f_0, f_1, bc_mask, missing_mask)
+    o_bm, o_mm = orc.build_masks((8, 6, 8), lat, obcs)
+    exp = orc.apply_bc(obcs[2], pre, post, o_bm, o_mm, lat, "FP32FP32")
+    assert np.array_equal(out.numpy(), exp)
+    assert not np.array_equal(exp, post)

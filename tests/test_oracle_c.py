@@ -70,3 +70,34 @@ def test_oracle_reproduces_committed_goldens():
     lat2, shape2, bcs2 = orc.cavity_2d(16)
     bc_mask, missing = orc.build_masks(shape2, lat2, bcs2)
     assert np.array_equal(bc_mask, g2["bc_mask"]) and np.array_equal(missing.astype(np.uint8), g2["missing_mask"])
+
+
+def test_outflow_auxiliary_data_matches_per_cell_restatement():
+    """oracle.assemble_auxiliary_data is roll-based like the reference (bc_extrapolation_outflow.py:104-134); check it
+    against the per-cell statement the HIP kernel implements: at an outflow cell b with outward normal n, every
+    direction l whose opposite is missing gets cs * ps[opp l](b - n) + (1 - cs) * ps[opp l](b), ps = post-stream."""
+    from oracle import xlb_numpy as orc
+
+    lat = orc.Lattice("D3Q19")
+    shape = (7, 5, 6)
+    box = orc.bounding_box_indices(shape, remove_edges=True)
+    bc = orc.BC(orc.KIND_EXTRAPOLATION_OUTFLOW, 3, box["top"])
+    assert bc.normal.tolist() == [0, 0, 1]
+    low = orc.BC(orc.KIND_EXTRAPOLATION_OUTFLOW, 4, box["left"])
+    assert low.normal.tolist() == [-1, 0, 0]
+    bm, mm = orc.build_masks(shape, lat, [bc])
+    rng = np.random.default_rng(0)
+    ps = rng.random((19,) + shape).astype(np.float32)
+    pc = rng.random((19,) + shape).astype(np.float32)
+    got = orc.assemble_auxiliary_data(bc, ps, pc, bm, mm, lat)
+    exp = pc.copy()
+    cs = np.float32(1.0) / np.sqrt(np.float32(3.0))
+    for x, y, z in zip(*[np.asarray(v) for v in box["top"]]):
+        for l in range(19):
+            o = lat.opp[l]
+            if mm[o, x, y, z]:
+                exp[l, x, y, z] = cs * ps[o, x, y, z - 1] + (np.float32(1.0) - cs) * ps[o, x, y, z]
+    assert np.array_equal(got, exp) and not np.array_equal(got, pc)
+    # every other BC kind leaves the post-collision populations alone (boundary_condition.py:138-144)
+    wall = orc.BC(orc.KIND_HALFWAY_BB, 5, box["bottom"])
+    assert orc.assemble_auxiliary_data(wall, ps, pc, bm, mm, lat) is pc

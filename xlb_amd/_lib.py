@@ -20,6 +20,7 @@ D2Q9, D3Q19, D3Q27 = 0, 1, 2
 BGK, KBC, SMAGORINSKY_LES_BGK = 0, 1, 2
 BC_EQUILIBRIUM, BC_HALFWAY_BB, BC_FULLWAY_BB, BC_DO_NOTHING = 1, 2, 3, 4
 BC_ZOUHE_VELOCITY, BC_ZOUHE_PRESSURE, BC_REGULARIZED_VELOCITY, BC_REGULARIZED_PRESSURE = 5, 6, 7, 8
+BC_EXTRAPOLATION_OUTFLOW = 9
 UNIQUE_ID_BYTES = 128
 
 NP_OF_DTYPE = {F64: np.float64, F32: np.float32, F16: np.float16, U8: np.uint8, BOOL: np.bool_, MISSING: np.uint8}

@@ -473,7 +473,7 @@ int xlbhip_apply_bc(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* b
   XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_post), "bc: bad bc_mask field");
   XLB_REQUIRE(same_grid(f_pre, f_post), "bc: grids differ");
   XLB_REQUIRE(bc->id >= 1 && bc->id <= 255, "bc id %d out of range", bc->id);
-  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_REGULARIZED_PRESSURE, "unknown bc kind %d", bc->kind);
+  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_EXTRAPOLATION_OUTFLOW, "unknown bc kind %d", bc->kind);
   if (bc->kind == XLBHIP_BC_HALFWAY_BB || bc->kind >= XLBHIP_BC_ZOUHE_VELOCITY)
     XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_post), "bc: this boundary condition needs a missing_mask field");
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
@@ -569,6 +569,7 @@ struct xlbhip_stepper {
   int n_bc = 0;
   bool needs_missing = false;
   bool extended_bcs = false;
+  bool has_outflow = false;  // ExtrapolationOutflowBC present: k_outflow_aux runs after every step
   uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
   int order_ty = 0, order_tz = 0;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
@@ -790,8 +791,8 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
   return 0;
 }
 
-// one step src -> dst, with the slab halo protocol when the fields carry ghost planes
-static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+// the step kernel(s) of one step src -> dst, with the slab halo protocol when the fields carry ghost planes
+static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                      double omega) {
   xlbhip_ctx* c = s->ctx;
   StepLaunch p = make_launch(s, src, dst, bcm, miss, omega);
@@ -829,6 +830,26 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
   return launch_any(s, p);
 }
 
+// one step src -> dst; ExtrapolationOutflowBC cells get their auxiliary data afterwards (nse_stepper.py:270-272)
+static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
+                     double omega) {
+  if (int rc = step_kernels(s, src, dst, bcm, miss, omega)) return rc;
+  if (!s->has_outflow) return 0;
+  xlbhip_ctx* c = s->ctx;
+  const size_t n = dst->cells();
+  return by_lattice(s->lattice, [&](auto L) {
+    using LL = decltype(L);
+    if (s->cdt == XLBHIP_F32)
+      hipLaunchKernelGGL((k_outflow_aux<LL, float>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
+                         s->tab_kind, static_cast<const float*>(s->tab_values));
+    else
+      hipLaunchKernelGGL((k_outflow_aux<LL, double>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
+                         s->tab_kind, static_cast<const double*>(s->tab_values));
+    XLB_HIP(hipGetLastError());
+    return 0;
+  });
+}
+
 }  // namespace xlb
 
 extern "C" {
@@ -845,11 +866,12 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   std::vector<uint8_t> kind(256, 0);
   const int q = lattice_q(lattice);
   std::vector<double> vals(256 * 27, 0.0);
-  bool needs_missing = false, extended = false;
+  bool needs_missing = false, extended = false, has_outflow = false;
   for (int i = 0; i < n_bc; ++i) {
     const xlbhip_bc_desc& b = bcs[i];
     XLB_REQUIRE(b.id >= 1 && b.id <= 255, "bc id %d out of range 1..255", b.id);
-    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_REGULARIZED_PRESSURE, "unknown bc kind %d", b.kind);
+    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_EXTRAPOLATION_OUTFLOW, "unknown bc kind %d", b.kind);
+    if (b.kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) has_outflow = true;
     XLB_REQUIRE(kind[b.id] == 0, "bc id %d used twice", b.id);
     if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY) extended = needs_missing = true;
     kind[b.id] = (uint8_t)b.kind;
@@ -876,6 +898,7 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   s->n_bc = n_bc;
   s->needs_missing = needs_missing;
   s->extended_bcs = extended;
+  s->has_outflow = has_outflow;
   s->ids_packed = ids_packed;
   s->kinds_packed = kinds_packed;
   s->moving_mask = moving_mask;

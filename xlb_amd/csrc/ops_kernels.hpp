@@ -172,7 +172,7 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
   const size_t ip = cell_index(f_pre, d, x, y, z), io = cell_index(f_post, d, x, y, z);
   unsigned m = 0;
   if (kind == XLBHIP_BC_HALFWAY_BB || kind >= XLBHIP_BC_ZOUHE_VELOCITY) m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
-  if (kind >= XLBHIP_BC_ZOUHE_VELOCITY) {
+  if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
     T ff[L::Q], val[3];
     static_for<L::Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
@@ -198,11 +198,88 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
       if ((m >> l) & 1u)
         store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io,
                     load_rt<T>(f_pre, (size_t)o * f_pre.plane_stride + ip) + static_cast<T>(vals.v[l]));
+    } else if (kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) {
+      // bc_extrapolation_outflow.py:137-145 (streaming step; the extrapolation itself is k_outflow_aux)
+      if ((m >> l) & 1u) store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, load_rt<T>(f_pre, (size_t)o * f_pre.plane_stride + ip));
     } else if (kind == XLBHIP_BC_FULLWAY_BB) {
       store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, load_rt<T>(f_pre, (size_t)o * f_pre.plane_stride + ip));
     } else if (kind == XLBHIP_BC_DO_NOTHING) {
       store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, load_rt<T>(f_pre, (size_t)l * f_pre.plane_stride + ip));
     }
+  });
+}
+
+// ---- ExtrapolationOutflowBC: auxiliary data after the collision --------------------------
+// Post-stream populations of ONE cell: periodic pull + the STREAMING-step boundary condition of that cell
+// (nse_stepper.py:246-257).  Generic slow path: only the outflow cells and the cells behind them run it.
+template <class L, class T>
+__device__ void post_stream_cell(const FieldView& f0, const FieldView& bc, const FieldView& miss, const Dims& d, const uint8_t* kind_tab,
+                                 const T* val_tab, int x, int y, int z, T (&f)[L::Q]) {
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    const int xs = f0.halo ? x - L::c(0, l) : wrap(x - L::c(0, l), d.nx);
+    const int ys = wrap(y - L::c(1, l), d.ny);
+    const int zs = wrap(z - L::c(2, l), d.nz);
+    f[l] = load_rt<T>(f0, (size_t)l * f0.plane_stride + cell_index(f0, d, xs, ys, zs));
+  });
+  const unsigned id = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+  if (id == 0u) return;
+  const unsigned kind = kind_tab[id];
+  const T* val = val_tab + id * 27u;
+  const size_t own = cell_index(f0, d, x, y, z);
+  unsigned m = 0;
+  if (miss.data) m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+  if (kind == XLBHIP_BC_EQUILIBRIUM) {
+    static_for<L::Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
+  } else if (kind == XLBHIP_BC_HALFWAY_BB) {
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      if ((m >> l) & 1u) f[l] = load_rt<T>(f0, (size_t)opp<L>(l) * f0.plane_stride + own) + val[l];
+    });
+  } else if (kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) {
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      if ((m >> l) & 1u) f[l] = load_rt<T>(f0, (size_t)opp<L>(l) * f0.plane_stride + own);
+    });
+  } else if (kind == XLBHIP_BC_DO_NOTHING) {
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      f[l] = load_rt<T>(f0, (size_t)l * f0.plane_stride + own);
+    });
+  } else if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
+    zouhe_cell<L, T>(f, m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
+                     kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
+  }
+}
+
+// assemble_auxiliary_data of ExtrapolationOutflowBC (bc_extrapolation_outflow.py:104-134), run after the step kernel:
+// at an outflow cell b with outward normal n, for every direction l whose opposite is missing,
+//   f_1[l](b) = cs * f_post_stream[opp l](b - n) + (1 - cs) * f_post_stream[opp l](b)
+template <class L, class T>
+__global__ void k_outflow_aux(FieldView f0, FieldView f1, FieldView bc, FieldView miss, Dims d, const uint8_t* kind_tab, const T* val_tab) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const unsigned id = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+  if (id == 0u || kind_tab[id] != XLBHIP_BC_EXTRAPOLATION_OUTFLOW) return;
+  const T* val = val_tab + id * 27u;
+  const int n0 = (int)val[0], n1 = (int)val[1], n2 = (int)val[2];
+  const T cs = val[3], omcs = val[4];
+  int xn = x - n0;
+  if (f0.halo) {
+    if (xn < 0 || xn >= d.nx) return;  // the cell behind the face lives on another rank: outflow faces must be domain faces
+  } else {
+    xn = wrap(xn, d.nx);
+  }
+  const int yn = wrap(y - n1, d.ny), zn = wrap(z - n2, d.nz);
+  T fb[L::Q], fn[L::Q];
+  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, x, y, z, fb);
+  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, xn, yn, zn, fn);
+  const unsigned m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+  const size_t o1 = cell_index(f1, d, x, y, z);
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int o = opp<L>(l);
+    if ((m >> o) & 1u) store_rt<T>(f1, (size_t)l * f1.plane_stride + o1, cs * fn[o] + omcs * fb[o]);
   });
 }
 
@@ -284,7 +361,7 @@ __global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* 
         kind = (kinds_packed >> (4 * s)) & 0xfu;
         slot = (unsigned)s;
       }
-    if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 9u;
+    if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 15u;  // K_HW_MOVING (step2_kernel.hpp)
     w = kind | (slot << 4) | ((miss ? miss[i] : 0u) << 8);
   }
   meta[i] = w;

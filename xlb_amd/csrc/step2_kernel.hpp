@@ -39,7 +39,7 @@ struct S2Geom {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // meta word (built per run by k_build_meta): kind | slot << 4 | missing << 8
-constexpr unsigned K_HW_MOVING = 9;
+constexpr unsigned K_HW_MOVING = 15;  // internal to the meta word (4 bits); the public kinds end at 9
 __device__ __forceinline__ unsigned meta_kind(unsigned w) { return w & 0xfu; }
 __device__ __forceinline__ unsigned meta_slot(unsigned w) { return (w >> 4) & 0xfu; }
 

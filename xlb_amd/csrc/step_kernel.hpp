@@ -311,7 +311,17 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
           fullway = true;
         } else if constexpr (HASBC == 2) {
           // extended kernel variant only: Zou-He / Regularized inlets and outlets (bc_zouhe.py, bc_regularized.py)
-          if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
+          if (kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) {
+            // bc_extrapolation_outflow.py:137-145: missing & boundary -> f_pre[opp] (last step's auxiliary data; the
+            // new ones are assembled by k_outflow_aux after this kernel)
+            const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
+            const unsigned cbo = opaque(cb);
+            static_for<Q>([&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              const S* own = a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)Xs[1] * plane_cells;  // uniform
+              if ((m >> l) & 1u) f[k][l] = to_compute<T, S>(ld(own, cbo));
+            });
+          } else if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
             const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
             const T* val = opaque(a.bc_values + id * 27u);
             zouhe_cell<L, T>(f[k], m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,

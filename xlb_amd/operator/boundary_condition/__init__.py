@@ -8,4 +8,5 @@ from .boundary_condition import (
     DoNothingBC as DoNothingBC,
     ZouHeBC as ZouHeBC,
     RegularizedBC as RegularizedBC,
+    ExtrapolationOutflowBC as ExtrapolationOutflowBC,
 )

@@ -266,3 +266,52 @@ class RegularizedBC(ZouHeBC):
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
         return self._apply(f_pre, f_post, bc_mask, missing_mask)
+
+
+class ExtrapolationOutflowBC(BoundaryCondition):
+    """Outflow by first-order extrapolation from the interior (Geier et al. 2015), JAX semantics of the reference
+    (xlb/operator/boundary_condition/bc_extrapolation_outflow.py:36-145):
+
+    * ONE outward normal per BC object, deduced from the index lists (``_get_normal_vectors``, :78-92);
+    * streaming step: the missing populations take the cell's own opposite pre-stream population — which holds the
+      auxiliary data written by the previous step;
+    * after the collision (``assemble_auxiliary_data``, :104-134) the outgoing populations are overwritten with
+      ``cs * f_post_stream(cell - normal) + (1 - cs) * f_post_stream(cell)``, cs = 1/sqrt(3) in the compute dtype.
+
+    The fused stepper does the first part inside the step kernel and the second in a small pass over the outflow
+    cells right after it.  The face must be a face of the (global) domain."""
+
+    hip_kind = _lib.BC_EXTRAPOLATION_OUTFLOW
+
+    def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None, indices=None, mesh_vertices=None,
+                 voxelization_method=None):
+        super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
+                         voxelization_method)
+        if indices is None:
+            raise ValueError("ExtrapolationOutflowBC needs indices (its normal is deduced from them)")
+        self._get_normal_vectors(indices)
+
+    def _get_normal_vectors(self, indices):
+        """bc_extrapolation_outflow.py:78-92: the axis whose most common coordinate occurs most often is the normal
+        axis; it points outward (negative when that coordinate is 0)."""
+        from collections import Counter
+
+        freq_counts = [Counter(int(v) for v in coord).most_common(1)[0] for coord in indices]
+        counts = np.array([count for _, count in freq_counts])
+        elements = np.array([element for element, _ in freq_counts])
+        self.normal = counts // counts.max()
+        if elements[np.argmax(counts)] == 0:
+            self.normal = self.normal * -1
+
+    def _hip_values(self):
+        T = self.compute_dtype
+        out = np.zeros(27)
+        out[3 - self.velocity_set.d : 3] = self.normal  # internal 3-component form
+        cs = T(1.0) / np.sqrt(T(3.0))
+        out[3] = float(cs)
+        out[4] = float(T(1.0) - cs)
+        return out
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        return self._apply(f_pre, f_post, bc_mask, missing_mask)
