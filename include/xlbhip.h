@@ -134,6 +134,13 @@ int xlbhip_macroscopic(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xl
                        xlbhip_field* u);
 /* SecondMoment()(f, pi): second_moment.py:35-55 */
 int xlbhip_second_moment(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_field* f, xlbhip_field* pi);
+/* Vorticity()(u, bc_mask, vorticity, vorticity_magnitude): postprocess/vorticity.py:30-93 (3-D; cells one layer inside the
+ * box whose six face neighbours are all fluid get the curl of u by central differences and its magnitude; every other cell of
+ * the outputs is left untouched).  Arithmetic in u's dtype (fp32 / fp64). */
+int xlbhip_vorticity(xlbhip_ctx* ctx, const xlbhip_field* u, const xlbhip_field* bc_mask, xlbhip_field* vorticity,
+                     xlbhip_field* vorticity_magnitude);
+/* QCriterion()(u, bc_mask, norm_mu, q): postprocess/q_criterion.py:36-139; Q = (|Omega|^2 - |S|^2) / 2, same cells */
+int xlbhip_q_criterion(xlbhip_ctx* ctx, const xlbhip_field* u, const xlbhip_field* bc_mask, xlbhip_field* norm_mu, xlbhip_field* q);
 /* BGK()/KBC()(f, feq, fout, omega): bgk.py:27-32,:78-91; kbc.py:40-79 */
 int xlbhip_collide(xlbhip_ctx* ctx, int lattice, int collision, int compute_dtype, const xlbhip_field* f,
                    const xlbhip_field* feq, xlbhip_field* fout, double omega);

@@ -619,3 +619,59 @@ def perturbed_init(shape, lat, policy="FP32FP32", seed=0, amp_rho=0.01, amp_u=0.
     rho = (1.0 + amp_rho * rng.uniform(-1, 1, size=(1,) + tuple(shape))).astype(T)
     u = (amp_u * rng.uniform(-1, 1, size=(lat.d,) + tuple(shape))).astype(T)
     return equilibrium(rho, u, lat, T).astype(store_dtype(policy))
+
+
+# ---- post-processing (xlb/operator/postprocess/vorticity.py:30-84, q_criterion.py:36-131) -------------------------
+def _velocity_gradient(u, bc_mask):
+    """Central differences on the cells one layer inside the box; `ok` marks the cells the reference's kernels write
+    (all six face neighbours fluid).  u: (3, nx, ny, nz)."""
+    T = u.dtype.type
+    c = (slice(1, -1),) * 3
+    b = bc_mask[0]
+    ok = (b[2:, 1:-1, 1:-1] == 0) & (b[1:-1, 2:, 1:-1] == 0) & (b[1:-1, 1:-1, 2:] == 0) & (b[:-2, 1:-1, 1:-1] == 0) & (b[1:-1, :-2, 1:-1] == 0) & (b[1:-1, 1:-1, :-2] == 0)
+
+    def d(a, axis):
+        hi = [slice(1, -1)] * 3
+        lo = [slice(1, -1)] * 3
+        hi[axis] = slice(2, None)
+        lo[axis] = slice(None, -2)
+        return (u[a][tuple(hi)] - u[a][tuple(lo)]) / T(2.0)
+
+    g = [[d(a, axis) for axis in range(3)] for a in range(3)]  # g[a][axis] = du_a / dx_axis
+    return g, ok, c
+
+
+def vorticity(u, bc_mask, vort, mag):
+    """Vorticity()(u, bc_mask, vorticity, vorticity_magnitude): returns updated copies of (vorticity, magnitude)."""
+    g, ok, c = _velocity_gradient(u, bc_mask)
+    vx = g[2][1] - g[1][2]
+    vy = g[0][2] - g[2][0]
+    vz = g[1][0] - g[0][1]
+    m = np.sqrt((vx * vx + vy * vy) + vz * vz)
+    vort, mag = vort.copy(), mag.copy()
+    for a, v in enumerate((vx, vy, vz)):
+        vort[a][c] = np.where(ok, v, vort[a][c])
+    mag[0][c] = np.where(ok, m, mag[0][c])
+    return vort, mag
+
+
+def q_criterion(u, bc_mask, norm_mu, q):
+    """QCriterion()(u, bc_mask, norm_mu, q): returns updated copies of (norm_mu, q)."""
+    T = u.dtype.type
+    g, ok, c = _velocity_gradient(u, bc_mask)
+    vx = g[2][1] - g[1][2]
+    vy = g[0][2] - g[2][0]
+    vz = g[1][0] - g[0][1]
+    m = np.sqrt((vx * vx + vy * vy) + vz * vz)
+    h = T(0.5)
+    s01, s02, s12 = h * (g[0][1] + g[1][0]), h * (g[0][2] + g[2][0]), h * (g[1][2] + g[2][1])
+    ss = _seq_sum_arrays([g[0][0] * g[0][0], s01 * s01, s02 * s02, s01 * s01, g[1][1] * g[1][1], s12 * s12, s02 * s02, s12 * s12, g[2][2] * g[2][2]])
+    o01, o02, o12 = h * (g[0][1] - g[1][0]), h * (g[0][2] - g[2][0]), h * (g[1][2] - g[2][1])
+    z = np.zeros_like(o01)
+    oo = _seq_sum_arrays([z, o01 * o01, o02 * o02, (-o01) * (-o01), z, o12 * o12, (-o02) * (-o02), (-o12) * (-o12), z])
+    qv = h * (oo - ss)
+    norm_mu, q = norm_mu.copy(), q.copy()
+    norm_mu[0][c] = np.where(ok, m, norm_mu[0][c])
+    q[0][c] = np.where(ok, qv, q[0][c])
+    return norm_mu, q
+

@@ -1,0 +1,52 @@
+"""Worker of tests/test_gpu_postprocess.py::test_zero_copy_export_to_torch: a fresh process that initialises
+PyTorch's HIP runtime FIRST (the wheel bundles its own; libxlbhip.so then binds to the one already loaded — the other
+order leaves torch with "No HIP GPUs are available")."""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+torch.cuda.init()
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _util import init_hip  # noqa: E402
+from xlb_amd.grid import grid_factory  # noqa: E402
+from xlb_amd.precision_policy import Precision  # noqa: E402
+
+
+def main():
+    init_hip("D3Q19")
+    for cfg, shape in ((None, (6, 8, 16)), ({"halo": 2}, (6, 8, 16))):
+        grid = grid_factory(shape, backend_config=cfg)
+        f = grid.create_field(19)
+        ref = np.random.default_rng(1).random((19,) + shape).astype(np.float32)
+        f.assign(ref)
+        t = torch.from_dlpack(f)
+        assert t.is_cuda and tuple(t.shape) == (19,) + shape and t.dtype == torch.float32
+        assert np.array_equal(t.cpu().numpy(), ref)
+        t2 = torch.as_tensor(f, device="cuda")  # CUDA array interface
+        assert t2.data_ptr() == t.data_ptr() and np.array_equal(t2.cpu().numpy(), ref)
+        # aliasing, both ways
+        t[3, 1, 2, 5] = 42.0
+        torch.cuda.synchronize()
+        assert f.numpy()[3, 1, 2, 5] == 42.0
+        f.fill(0.5)
+        f.ctx.sync()
+        assert float(t.sum().item()) == 0.5 * ref.size
+        # a reduction the backend has no operator for, straight on the field's memory: total mass
+        f.assign(ref)
+        assert abs(float(t.double().sum().item()) - float(ref.astype(np.float64).sum())) < 1e-6
+    init_hip("D2Q9")
+    g2 = grid_factory((8, 16))
+    m = g2.create_field(1, dtype=Precision.UINT8, fill_value=3)
+    tm = torch.from_dlpack(m)
+    assert tuple(tm.shape) == (1, 8, 16) and tm.dtype == torch.uint8 and int(tm.sum().item()) == 3 * 128
+    print("DLPACK_OK")  # (t, t2, tm die at interpreter shutdown: the deleter thunk is built to survive that)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,3 +23,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _fresh_bc_registry():
+    """Boundary-condition ids are a process-global counter in construction order (boundary_condition.py:68 in the
+    reference, same here) and bc_mask is uint8: one pytest process builds more than 253 BCs, so every test starts
+    with the registry of a fresh process — which is also what makes ids like lid=1, walls=2 deterministic."""
+    from xlb_amd.operator.boundary_condition import boundary_condition_registry
+
+    boundary_condition_registry.__init__()
+    yield

@@ -64,6 +64,8 @@ SIGNATURES = {
     "xlbhip_equilibrium": [_p, _i, _i, _p, _p, _p],
     "xlbhip_macroscopic": [_p, _i, _i, _p, _p, _p],
     "xlbhip_second_moment": [_p, _i, _i, _p, _p],
+    "xlbhip_vorticity": [_p, _p, _p, _p, _p],
+    "xlbhip_q_criterion": [_p, _p, _p, _p, _p],
     "xlbhip_collide": [_p, _i, _i, _i, _p, _p, _p, _d],
     "xlbhip_apply_bc": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, _p],
     "xlbhip_build_masks": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p],
@@ -177,6 +179,70 @@ def comm_unique_id():
     return buf.raw
 
 
+# ---- DLPack (dlpack.h v0.8 ABI) through ctypes: no extension module needed ---------------------------------
+class _DLDevice(C.Structure):
+    _fields_ = [("device_type", C.c_int), ("device_id", C.c_int)]
+
+
+class _DLDataType(C.Structure):
+    _fields_ = [("code", C.c_uint8), ("bits", C.c_uint8), ("lanes", C.c_uint16)]
+
+
+class _DLTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("device", _DLDevice), ("ndim", C.c_int), ("dtype", _DLDataType),
+                ("shape", C.POINTER(C.c_int64)), ("strides", C.POINTER(C.c_int64)), ("byte_offset", C.c_uint64)]
+
+
+class _DLManagedTensor(C.Structure):
+    pass
+
+
+_DL_DELETER = C.CFUNCTYPE(None, C.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", C.c_void_p), ("deleter", _DL_DELETER)]
+_dl_alive = {}  # address of the managed tensor -> (managed tensor, shape/stride arrays, owner): kept until the consumer's deleter runs
+
+
+@_DL_DELETER
+def _dl_deleter(handle):
+    try:
+        _dl_alive.pop(C.addressof(handle.contents), None)
+    except Exception:  # interpreter shutdown: the module globals may already be gone
+        pass
+
+
+# A consumer may drop its last tensor during interpreter finalisation, after this module's globals were cleared: the
+# native thunk of the deleter must outlive everything, so it is leaked on purpose.
+C.pythonapi.Py_IncRef(C.py_object(_dl_deleter))
+
+
+# The capsule destructor runs while the capsule is being deallocated (reference count 0): it must see the raw
+# PyObject* — a ctypes py_object argument would INCREF / DECREF the dying object and free it twice.
+_PyCapsule_IsValid = C.PYFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p)(("PyCapsule_IsValid", C.pythonapi))
+_PyCapsule_GetPointer = C.PYFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p)(("PyCapsule_GetPointer", C.pythonapi))
+_PyCapsule_New = C.PYFUNCTYPE(C.py_object, C.c_void_p, C.c_char_p, C.c_void_p)(("PyCapsule_New", C.pythonapi))
+
+
+@C.PYFUNCTYPE(None, C.c_void_p)
+def _dl_capsule_destructor(capsule_ptr):
+    # a capsule nobody consumed still carries the name "dltensor": release what it points to
+    if _PyCapsule_IsValid(capsule_ptr, b"dltensor"):
+        _dl_alive.pop(_PyCapsule_GetPointer(capsule_ptr, b"dltensor"), None)
+
+
+def _dlpack_capsule(owner, ptr, shape, strides, dtype, device_id):
+    nd = len(shape)
+    shp = (C.c_int64 * nd)(*shape)
+    std = (C.c_int64 * nd)(*strides)  # DLPack strides are in elements
+    code = {"f": 2, "u": 1, "i": 0, "b": 6}[np.dtype(dtype).kind]
+    m = _DLManagedTensor()
+    m.dl_tensor = _DLTensor(C.c_void_p(ptr), _DLDevice(10, int(device_id)), nd, _DLDataType(code, np.dtype(dtype).itemsize * 8, 1),
+                            C.cast(shp, C.POINTER(C.c_int64)), C.cast(std, C.POINTER(C.c_int64)), 0)
+    m.manager_ctx = None
+    m.deleter = _dl_deleter
+    _dl_alive[C.addressof(m)] = (m, shp, std, owner)
+    return _PyCapsule_New(C.addressof(m), b"dltensor", C.cast(_dl_capsule_destructor, C.c_void_p))
+
+
 class Field:
     """A device-resident field.  Host-visible shape is (cardinality, nx, ny[, nz]) C-order,
     exactly the reference layout; the device layout is private."""
@@ -218,6 +284,37 @@ class Field:
         out = np.empty(self.shape, dtype=self.dtype)
         check(load().xlbhip_field_download(self.handle, out.ctypes.data, out.nbytes))
         return out
+
+    # -- zero-copy export (what replaces the reference's ToJAX / warp_array_to_jax helpers, utils/utils.py:340-447):
+    #    the interior of the field as a strided (cardinality, nx, ny[, nz]) device array.  The population planes are
+    #    `plane_stride` elements apart (padding, ghost planes), which strides express exactly.
+    def _device_view(self):
+        if self.dtype_code == MISSING:
+            raise HipBackendError("the bit-packed missing_mask has no array view; use numpy()")
+        info = self.info()
+        item = self.dtype.itemsize
+        ny, nz = self._s3[1], self._s3[2]
+        ptr = info["device_ptr"] + self.halo * ny * nz * item
+        strides = (info["plane_stride"], ny * nz, nz, 1) if len(self.grid_shape) == 3 else (info["plane_stride"], nz, 1)
+        return ptr, self.shape, strides, item
+
+    @property
+    def __cuda_array_interface__(self):
+        """CUDA Array Interface v3 (PyTorch-ROCm, CuPy-ROCm and Numba consume it): ``torch.as_tensor(field, device="cuda")``
+        aliases the field's memory.  Work enqueued on the backend's stream is finished first."""
+        ptr, shape, strides, item = self._device_view()
+        self.ctx.sync()
+        return {"shape": shape, "strides": tuple(s * item for s in strides), "typestr": self.dtype.str, "data": (ptr, False), "version": 3}
+
+    def __dlpack_device__(self):
+        return (10, self.ctx.device)  # kDLROCM
+
+    def __dlpack__(self, stream=None, **_):
+        """DLPack capsule of the same strided view (``torch.from_dlpack(field)``).  The consumer's stream is not known to
+        this backend, so the backend's own stream is drained before the capsule is handed out."""
+        ptr, shape, strides, item = self._device_view()
+        self.ctx.sync()
+        return _dlpack_capsule(self, ptr, shape, strides, self.dtype, self.ctx.device)
 
     def __array__(self, dtype=None, copy=None):
         a = self.numpy()

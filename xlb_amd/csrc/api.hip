@@ -90,6 +90,25 @@ static int collide_launch(xlbhip_ctx* c, int coll, const xlbhip_field* f, const 
   return 0;
 }
 
+template <int MODE>
+static int velocity_gradient_launch(xlbhip_ctx* c, const xlbhip_field* u, const xlbhip_field* bcm, xlbhip_field* out_a, xlbhip_field* out_b,
+                                    const char* what) {
+  XLB_REQUIRE(c && u && bcm && out_a && out_b, "%s: null argument", what);
+  XLB_REQUIRE(u->card == 3 && (u->dtype == XLBHIP_F32 || u->dtype == XLBHIP_F64), "%s: u must be a (3, nx, ny, nz) fp32 / fp64 field", what);
+  XLB_REQUIRE(u->halo == 0, "%s: fields with ghost planes are not supported (single-rank post-processing, like the reference)", what);
+  XLB_REQUIRE(bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, u) && bcm->halo == 0, "%s: bad bc_mask field", what);
+  XLB_REQUIRE(out_a->card == (MODE == 0 ? 3 : 1) && out_b->card == 1 && is_float(out_a->dtype) && is_float(out_b->dtype) &&
+                  same_grid(out_a, u) && same_grid(out_b, u) && out_a->halo == 0 && out_b->halo == 0,
+              "%s: bad output fields", what);
+  const size_t n = u->cells();
+  if (u->dtype == XLBHIP_F32)
+    hipLaunchKernelGGL((k_velocity_gradient<float, MODE>), blocks_for(n), 256, 0, c->stream, view(u), view(bcm), view(out_a), view(out_b), dims(u));
+  else
+    hipLaunchKernelGGL((k_velocity_gradient<double, MODE>), blocks_for(n), 256, 0, c->stream, view(u), view(bcm), view(out_a), view(out_b), dims(u));
+  XLB_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" {
 
 const char* xlbhip_last_error(void) { return g_err.c_str(); }
@@ -430,6 +449,14 @@ int xlbhip_macroscopic(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_field* 
     XLB_HIP(hipGetLastError());
     return 0;
   });
+}
+
+int xlbhip_vorticity(xlbhip_ctx* c, const xlbhip_field* u, const xlbhip_field* bcm, xlbhip_field* vorticity, xlbhip_field* magnitude) {
+  return velocity_gradient_launch<0>(c, u, bcm, vorticity, magnitude, "vorticity");
+}
+
+int xlbhip_q_criterion(xlbhip_ctx* c, const xlbhip_field* u, const xlbhip_field* bcm, xlbhip_field* norm_mu, xlbhip_field* q) {
+  return velocity_gradient_launch<1>(c, u, bcm, norm_mu, q, "q_criterion");
 }
 
 int xlbhip_second_moment(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_field* f, xlbhip_field* pi) {

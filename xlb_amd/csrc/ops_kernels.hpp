@@ -209,6 +209,66 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
   });
 }
 
+// ---- post-processing: Vorticity and QCriterion (postprocess/vorticity.py:30-84, q_criterion.py:36-131) ----
+// The reference has these for its kernel backend only: one thread per cell of the box shrunk by one cell per side,
+// nothing is written where any of the six face neighbours carries a boundary id, central differences elsewhere.
+// MODE 0: out_a = vorticity (3 components), out_b = |vorticity|;  MODE 1: out_a = |vorticity|, out_b = Q.
+template <class T, int MODE>
+__global__ void k_velocity_gradient(FieldView u, FieldView bc, FieldView out_a, FieldView out_b, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  if (x < 1 || y < 1 || z < 1 || x > d.nx - 2 || y > d.ny - 2 || z > d.nz - 2) return;
+  const uint8_t* b = static_cast<const uint8_t*>(bc.data);
+  if (b[cell_index(bc, d, x + 1, y, z)] != 0 || b[cell_index(bc, d, x, y + 1, z)] != 0 || b[cell_index(bc, d, x, y, z + 1)] != 0 ||
+      b[cell_index(bc, d, x - 1, y, z)] != 0 || b[cell_index(bc, d, x, y - 1, z)] != 0 || b[cell_index(bc, d, x, y, z - 1)] != 0)
+    return;
+  auto U = [&](int a, int i, int j, int k) { return load_rt<T>(u, (size_t)a * u.plane_stride + cell_index(u, d, i, j, k)); };
+  const T two = T(2.0), half = T(0.5);
+  const T u_x_dy = (U(0, x, y + 1, z) - U(0, x, y - 1, z)) / two;
+  const T u_x_dz = (U(0, x, y, z + 1) - U(0, x, y, z - 1)) / two;
+  const T u_y_dx = (U(1, x + 1, y, z) - U(1, x - 1, y, z)) / two;
+  const T u_y_dz = (U(1, x, y, z + 1) - U(1, x, y, z - 1)) / two;
+  const T u_z_dx = (U(2, x + 1, y, z) - U(2, x - 1, y, z)) / two;
+  const T u_z_dy = (U(2, x, y + 1, z) - U(2, x, y - 1, z)) / two;
+  const T vx = u_z_dy - u_y_dz, vy = u_x_dz - u_z_dx, vz = u_y_dx - u_x_dy;
+  const T mag = sqrt((vx * vx + vy * vy) + vz * vz);
+  const size_t oa = cell_index(out_a, d, x, y, z), ob = cell_index(out_b, d, x, y, z);
+  if constexpr (MODE == 0) {
+    store_rt<T>(out_a, oa, vx);
+    store_rt<T>(out_a, out_a.plane_stride + oa, vy);
+    store_rt<T>(out_a, 2 * out_a.plane_stride + oa, vz);
+    store_rt<T>(out_b, ob, mag);
+  } else {
+    const T u_x_dx = (U(0, x + 1, y, z) - U(0, x - 1, y, z)) / two;
+    const T u_y_dy = (U(1, x, y + 1, z) - U(1, x, y - 1, z)) / two;
+    const T u_z_dz = (U(2, x, y, z + 1) - U(2, x, y, z - 1)) / two;
+    const T s01 = half * (u_x_dy + u_y_dx), s02 = half * (u_x_dz + u_z_dx), s12 = half * (u_y_dz + u_z_dy);
+    // s_dot_s: the nine squares summed in row-major order, as the reference writes them
+    T ss = u_x_dx * u_x_dx;
+    ss = ss + s01 * s01;
+    ss = ss + s02 * s02;
+    ss = ss + s01 * s01;
+    ss = ss + u_y_dy * u_y_dy;
+    ss = ss + s12 * s12;
+    ss = ss + s02 * s02;
+    ss = ss + s12 * s12;
+    ss = ss + u_z_dz * u_z_dz;
+    const T o01 = half * (u_x_dy - u_y_dx), o02 = half * (u_x_dz - u_z_dx), o12 = half * (u_y_dz - u_z_dy);
+    const T o10 = -o01, o20 = -o02, o21 = -o12;
+    // omega_dot_omega: same order; the three 0.0**2 terms add exact zeros to non-negative partial sums
+    T oo = T(0.0) + o01 * o01;
+    oo = oo + o02 * o02;
+    oo = oo + o10 * o10;
+    oo = oo + T(0.0);
+    oo = oo + o12 * o12;
+    oo = oo + o20 * o20;
+    oo = oo + o21 * o21;
+    oo = oo + T(0.0);
+    store_rt<T>(out_a, oa, mag);
+    store_rt<T>(out_b, ob, half * (oo - ss));
+  }
+}
+
 // ---- ExtrapolationOutflowBC: auxiliary data after the collision --------------------------
 // Post-stream populations of ONE cell: periodic pull + the STREAMING-step boundary condition of that cell
 // (nse_stepper.py:246-257).  Generic slow path: only the outflow cells and the cells behind them run it.
