@@ -8,8 +8,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 30 --warmup 5 --cpu-baseline-seconds 0 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1
+# kernel trace: the default bench command (200 steps, 10 warm-up) minus the CPU-baseline leg; counters: a shorter run
+BENCH="python3 $ROOT/bench.py --steps 30 --warmup 6 --cpu-baseline-seconds 0 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py --cpu-baseline-seconds 0 $* > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 # calibration: copy kernels with known byte counts (10.2 GB each way), same counters
