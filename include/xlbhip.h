@@ -134,6 +134,10 @@ int xlbhip_macroscopic(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xl
                        xlbhip_field* u);
 /* SecondMoment()(f, pi): second_moment.py:35-55 */
 int xlbhip_second_moment(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_field* f, xlbhip_field* pi);
+/* as xlbhip_apply_bc for a Zou-He / Regularized BC with per-cell prescribed values (see xlbhip_stepper_set_bc_profile) */
+int xlbhip_apply_bc_profile(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_bc_desc* bc, const xlbhip_field* f_pre,
+                            xlbhip_field* f_post, const xlbhip_field* bc_mask, const xlbhip_field* missing_mask, int64_t n,
+                            const uint32_t* storage_cells, const double* values);
 /* Vorticity()(u, bc_mask, vorticity, vorticity_magnitude): postprocess/vorticity.py:30-93 (3-D; cells one layer inside the
  * box whose six face neighbours are all fluid get the curl of u by central differences and its magnitude; every other cell of
  * the outputs is left untouched).  Arithmetic in u's dtype (fp32 / fp64). */
@@ -167,6 +171,12 @@ int xlbhip_build_masks(xlbhip_ctx* ctx, int lattice, int n_bc, const int32_t* bc
 int xlbhip_stepper_create(xlbhip_ctx* ctx, int lattice, int collision, int compute_dtype, int store_dtype, int n_bc,
                           const xlbhip_bc_desc* bcs, xlbhip_stepper** out);
 int xlbhip_stepper_destroy(xlbhip_stepper* s);
+/* Per-cell prescribed values of a Zou-He / Regularized BC built with a profile (bc_zouhe.py:122-124,225-232: the
+ * array the profile returns, broadcast over the grid, evaluated at the BC's cells): storage_cells[i] =
+ * ((x_local + halo) * ny + y) * nz + z of a cell of bc_id on this rank, values[3 i .. 3 i + 2] = its velocity vector
+ * (internal 3-component form) or its density in values[3 i].  Replaces the kernel backends' encoding of these values in
+ * f_1 (helper_functions_bc.py:371-499, nse_stepper.py:398-425).  May be called once per BC; tables are merged. */
+int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const uint32_t* storage_cells, const double* values);
 /* ForcedCollision with the exact-difference scheme (forced_collision.py:44-50, exact_difference_force.py:61-83):
  * force[3] in the internal 3-component form; NULL switches forcing off */
 int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force);

@@ -459,13 +459,23 @@ def _zouhe(bc, f_post, boundary, missing, lat, policy):
         [np.where(known[l], f_post[l], T(0)) for l in range(q)]
     )
     velocity = bc.kind in (KIND_ZOUHE_VELOCITY, KIND_REGULARIZED_VELOCITY)
-    if velocity:
+    profile = np.ndim(bc.prescribed) > 1  # the array a profile() returned, to be broadcast (bc_zouhe.py:179-214)
+    if profile:
+        pv = np.asarray(bc.prescribed, dtype=np.float64).astype(S).astype(T)
+        if pv.ndim < d + 1:  # singleton axes are inserted right after the first one
+            pv = pv.reshape((pv.shape[0],) + (1,) * (d + 1 - pv.ndim) + pv.shape[1:])
+        pv = np.broadcast_to(pv, (pv.shape[0],) + f_post.shape[1:])
+    if velocity and profile:
+        vel = [pv[a] for a in range(d)]
+        unormal = _seq_sum([normals[a].astype(T) * vel[a] for a in range(d)])
+        rho = fsum / (T(1.0) + unormal)
+    elif velocity:
         pv = np.asarray(bc.prescribed, dtype=np.float64).astype(S).astype(T)  # bc_zouhe.py:155-156
         vel = [np.full(f_post.shape[1:], pv[a], dtype=T) for a in range(d)]
         unormal = _seq_sum([normals[a].astype(T) * vel[a] for a in range(d)])  # :263
         rho = fsum / (T(1.0) + unormal)  # :265
     else:
-        rho = np.full(f_post.shape[1:], T(S(bc.prescribed)), dtype=T)
+        rho = pv[0] if profile else np.full(f_post.shape[1:], T(S(bc.prescribed)), dtype=T)
         unormal = T(-1.0) + fsum / rho  # :250
         vel = [unormal * normals[a].astype(T) for a in range(d)]  # :253
     feq = equilibrium(rho[None], np.stack(vel), lat, T)

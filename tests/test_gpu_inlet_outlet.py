@@ -93,8 +93,8 @@ def test_argument_validation():
         ZouHeBC("velocity", prescribed_value=(0.1, 0.1, 0.0), indices=[[0], [0], [0]])  # only normal values
     with pytest.raises(ValueError):
         ZouHeBC("pressure", prescribed_value=(1.0, 0.0, 0.0), indices=[[0], [0], [0]])
-    with pytest.raises(NotImplementedError):
-        RegularizedBC("velocity", profile=lambda: None, indices=[[0], [0], [0]])
+    with pytest.raises(ValueError, match="callable"):
+        RegularizedBC("velocity", profile=np.zeros((3, 1)), indices=[[0], [0], [0]])
 
 
 # ---- ExtrapolationOutflowBC (bc_extrapolation_outflow.py, JAX semantics) --------------------------------------
@@ -182,3 +182,86 @@ def test_extrapolation_outflow_operator_call():
     exp = orc.apply_bc(obcs[2], pre, post, o_bm, o_mm, lat, "FP32FP32")
     assert np.array_equal(out.numpy(), exp)
     assert not np.array_equal(exp, post)
+
+
+# ---- callable profiles: per-cell prescribed values (bc_zouhe.py:122-124, :179-232) ---------------------------------
+def parabolic_inlet(shape, u_max=0.04):
+    """examples/cfd/flow_past_sphere_3d.py:64-81 in NumPy: u_x(y, z) parabolic, zero at the walls -> (3, ny, nz)"""
+    ny, nz = shape[1], shape[2]
+    y, z = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+    hy, hz = ny - 1.0, nz - 1.0
+    r2 = (2.0 * (y - hy / 2.0) / hy) ** 2 + (2.0 * (z - hz / 2.0) / hz) ** 2
+    ux = u_max * np.maximum(0.0, 1.0 - r2)
+    return np.stack([ux, np.zeros_like(ux), np.zeros_like(ux)])
+
+
+@pytest.mark.parametrize("cls,policy", [(RegularizedBC, "FP32FP32"), (ZouHeBC, "FP32FP32"), (RegularizedBC, "FP64FP64")])
+def test_flow_past_sphere_setup_vs_oracle(cls, policy):
+    """The boundary-condition set of examples/cfd/flow_past_sphere_3d.py:104-112: fullway walls, an inlet with a parabolic
+    PROFILE, extrapolation outflow and a halfway sphere in the interior (indices with padding) — against the oracle,
+    bit for bit.  The pressure-profile variant runs on the outlet of a second stepper."""
+    shape = (28, 14, 14)
+    vs, pp = init_hip("D3Q19", policy)
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    walls = [sum((box[f][i] for f in ("bottom", "top", "front", "back")), []) for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    x, y, z = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    sphere = np.where((x - 9) ** 2 + (y - 7) ** 2 + (z - 7) ** 2 < 3.2**2)
+    sphere = [s.tolist() for s in sphere]
+    prof = parabolic_inlet(shape)
+    b_w = FullwayBounceBackBC(indices=walls)
+    b_in = cls("velocity", profile=lambda: prof, indices=box_ne["left"])
+    b_out = ExtrapolationOutflowBC(indices=box_ne["right"])
+    b_s = HalfwayBounceBackBC(indices=sphere)
+    bcs = [b_w, b_in, b_out, b_s]
+    kind = orc.KIND_REGULARIZED_VELOCITY if cls is RegularizedBC else orc.KIND_ZOUHE_VELOCITY
+    obcs = [orc.BC(orc.KIND_FULLWAY_BB, b_w.id, walls), orc.BC(kind, b_in.id, box_ne["left"], prescribed=prof),
+            orc.BC(orc.KIND_EXTRAPOLATION_OUTFLOW, b_out.id, box_ne["right"]), orc.BC(orc.KIND_HALFWAY_BB, b_s.id, sphere)]
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    steps = 30
+    a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, steps)
+    with np.errstate(all="ignore"):
+        exp = orc.run(orc.initialize_eq(shape, lat, policy), o_bm, o_mm, obcs, 1.5, lat, steps, policy)
+    out = a.numpy()
+    assert np.array_equal(out, exp), f"max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out.astype(np.float64) - exp).max()}"
+    rho, u = orc.macroscopic(out.astype(orc.compute_dtype(policy)), lat)
+    assert u[0, 1, 7, 7] > 0.03 and abs(u[0, 1, 1, 1]) < 0.01  # the profile arrived: fast in the middle, slow near the walls
+    # stand-alone operator call with per-cell values
+    rng = np.random.default_rng(9)
+    T = orc.compute_dtype(policy)
+    post = (lat.w[:, None, None, None] * (1 + 0.05 * rng.standard_normal((19,) + shape))).astype(T)
+    f_1.assign(post)
+    got = b_in(f_0, f_1, bc_mask, missing_mask)
+    with np.errstate(all="ignore"):
+        e = orc.apply_bc(obcs[1], post, post, o_bm, o_mm, lat, policy)
+    assert np.array_equal(got.numpy(), e.astype(got.numpy().dtype))
+
+
+def test_pressure_profile_and_errors():
+    shape = (16, 8, 10)
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    rho_face = 1.0 + 0.01 * np.random.default_rng(2).random((1, shape[1], shape[2]))
+    b_in = ZouHeBC("velocity", prescribed_value=(0.02, 0.0, 0.0), indices=box_ne["left"])
+    b_out = ZouHeBC("pressure", profile=lambda: rho_face, indices=box_ne["right"])
+    obcs = [orc.BC(orc.KIND_ZOUHE_VELOCITY, b_in.id, box_ne["left"], prescribed=(0.02, 0.0, 0.0)),
+            orc.BC(orc.KIND_ZOUHE_PRESSURE, b_out.id, box_ne["right"], prescribed=rho_face)]
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_in, b_out])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.2, 12)
+    with np.errstate(all="ignore"):
+        exp = orc.run(orc.initialize_eq(shape, lat), o_bm, o_mm, obcs, 1.2, lat, 12)
+    assert np.array_equal(a.numpy(), exp)
+    with pytest.raises(ValueError, match="both profile and prescribed_value"):
+        ZouHeBC("velocity", profile=lambda: rho_face, prescribed_value=(0.1, 0, 0), indices=box_ne["left"])
+    with pytest.raises(ValueError, match="first axis"):
+        ZouHeBC("velocity", profile=lambda: rho_face, indices=box_ne["left"])

@@ -65,6 +65,8 @@ SIGNATURES = {
     "xlbhip_macroscopic": [_p, _i, _i, _p, _p, _p],
     "xlbhip_second_moment": [_p, _i, _i, _p, _p],
     "xlbhip_vorticity": [_p, _p, _p, _p, _p],
+    "xlbhip_stepper_set_bc_profile": [_p, _i, _i64, _p, _p],
+    "xlbhip_apply_bc_profile": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, _p, _i64, _p, _p],
     "xlbhip_q_criterion": [_p, _p, _p, _p, _p],
     "xlbhip_collide": [_p, _i, _i, _i, _p, _p, _p, _d],
     "xlbhip_apply_bc": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, _p],
@@ -411,6 +413,13 @@ class Stepper:
         else:
             arr = (C.c_double * 3)(*[float(x) for x in force3])
             check(load().xlbhip_stepper_set_force(self._h, C.cast(arr, C.c_void_p)))
+
+    def set_bc_profile(self, bc_id, storage_cells, values):
+        """Per-cell prescribed values of a Zou-He / Regularized BC: storage cell indices (uint32) and (n, 3) values."""
+        k = np.ascontiguousarray(storage_cells, dtype=np.uint32)
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, 3)
+        assert k.shape[0] == v.shape[0]
+        check(load().xlbhip_stepper_set_bc_profile(self._h, int(bc_id), int(k.shape[0]), k.ctypes.data, v.ctypes.data))
 
     def set_smagorinsky(self, coef):
         check(load().xlbhip_stepper_set_smagorinsky(self._h, float(coef)))

@@ -1,6 +1,10 @@
 // libxlbhip: C-ABI entry points (context, fields, whole-field operators, masker, stepper).
 // See include/xlbhip.h for the contract and the reference methods each call replaces.
+#include <algorithm>
+#include <array>
 #include <cstring>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "comm.hpp"
@@ -494,6 +498,12 @@ int xlbhip_collide(xlbhip_ctx* c, int lattice, int coll, int cdt, const xlbhip_f
 
 int xlbhip_apply_bc(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* bc, const xlbhip_field* f_pre, xlbhip_field* f_post,
                     const xlbhip_field* bcm, const xlbhip_field* miss) {
+  return xlbhip_apply_bc_profile(c, lattice, cdt, bc, f_pre, f_post, bcm, miss, 0, nullptr, nullptr);
+}
+
+int xlbhip_apply_bc_profile(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* bc, const xlbhip_field* f_pre, xlbhip_field* f_post,
+                            const xlbhip_field* bcm, const xlbhip_field* miss, int64_t n_prof, const uint32_t* storage_cells,
+                            const double* values) {
   XLB_REQUIRE(c && bc, "null argument");
   XLB_CHECK_POP(f_pre, lattice, "bc(f_pre)");
   XLB_CHECK_POP(f_post, lattice, "bc(f_post)");
@@ -507,17 +517,46 @@ int xlbhip_apply_bc(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* b
   BcValues vals;
   std::memcpy(vals.v, bc->values, sizeof(vals.v));
   const size_t n = f_post->cells();
-  return by_lattice(lattice, [&](auto L) {
+  // per-cell prescribed values (sorted by storage cell): uploaded for this call only — the stand-alone operator is
+  // not on the hot path
+  uint32_t* dk = nullptr;
+  double* dv = nullptr;
+  if (n_prof > 0) {
+    XLB_REQUIRE(storage_cells && values, "null profile table");
+    XLB_REQUIRE(bc->kind >= XLBHIP_BC_ZOUHE_VELOCITY && bc->kind <= XLBHIP_BC_REGULARIZED_PRESSURE, "profiles belong to Zou-He / Regularized BCs");
+    std::vector<std::pair<uint32_t, int64_t>> order((size_t)n_prof);
+    for (int64_t i = 0; i < n_prof; ++i) order[(size_t)i] = {storage_cells[i], i};
+    std::sort(order.begin(), order.end());
+    std::vector<uint32_t> keys((size_t)n_prof);
+    std::vector<double> v((size_t)n_prof * 3);
+    for (int64_t i = 0; i < n_prof; ++i) {
+      keys[(size_t)i] = order[(size_t)i].first;
+      for (int a = 0; a < 3; ++a) v[(size_t)i * 3 + a] = values[order[(size_t)i].second * 3 + a];
+    }
+    XLB_HIP(hipMalloc(&dk, keys.size() * sizeof(uint32_t)));
+    XLB_HIP(hipMalloc(&dv, v.size() * sizeof(double)));
+    XLB_HIP(hipMemcpyAsync(dk, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    XLB_HIP(hipMemcpyAsync(dv, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    XLB_HIP(hipStreamSynchronize(c->stream));  // the host vectors die with this scope
+  }
+  const int np = (int)n_prof;
+  int rc = by_lattice(lattice, [&](auto L) {
     using LL = decltype(L);
     if (cdt == XLBHIP_F32)
       hipLaunchKernelGGL((k_apply_bc<LL, float>), blocks_for(n), 256, 0, c->stream, bc->id, bc->kind, vals, view(f_pre), view(f_post),
-                         view(bcm), view(miss), dims(f_post));
+                         view(bcm), view(miss), dims(f_post), dk, dv, np);
     else
       hipLaunchKernelGGL((k_apply_bc<LL, double>), blocks_for(n), 256, 0, c->stream, bc->id, bc->kind, vals, view(f_pre), view(f_post),
-                         view(bcm), view(miss), dims(f_post));
+                         view(bcm), view(miss), dims(f_post), dk, dv, np);
     XLB_HIP(hipGetLastError());
     return 0;
   });
+  if (dk) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dk);
+    (void)hipFree(dv);
+  }
+  return rc;
 }
 
 // ---- masker -------------------------------------------------------------------------------
@@ -609,6 +648,12 @@ struct xlbhip_stepper {
   unsigned kinds_packed = 0;
   unsigned moving_mask = 0;     // slots (first 8 BCs) whose halfway wall has a non-zero moving-wall term
   void* tab_values = nullptr;   // device [256][27] compute dtype
+  // per-cell prescribed values of Zou-He / Regularized BCs built with a profile: host map (storage cell -> 3 values)
+  // and its sorted device image
+  std::map<uint32_t, std::array<double, 3>> prof_host;
+  uint32_t* prof_keys = nullptr;
+  void* prof_vals = nullptr;  // compute dtype [n_prof][3]
+  int n_prof = 0;
 };
 
 namespace xlb {
@@ -662,6 +707,9 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.kinds_packed = s->kinds_packed;
   p.n_bc = s->n_bc;
   p.tab_values = s->tab_values;
+  p.prof_keys = s->prof_keys;
+  p.prof_vals = s->prof_vals;
+  p.n_prof = s->n_prof;
   p.plane_stride = src->plane_stride;
   p.nx = src->nx;
   p.ny = src->ny;
@@ -868,10 +916,10 @@ static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* d
     using LL = decltype(L);
     if (s->cdt == XLBHIP_F32)
       hipLaunchKernelGGL((k_outflow_aux<LL, float>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
-                         s->tab_kind, static_cast<const float*>(s->tab_values));
+                         s->tab_kind, static_cast<const float*>(s->tab_values), s->prof_keys, static_cast<const float*>(s->prof_vals), s->n_prof);
     else
       hipLaunchKernelGGL((k_outflow_aux<LL, double>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
-                         s->tab_kind, static_cast<const double*>(s->tab_values));
+                         s->tab_kind, static_cast<const double*>(s->tab_values), s->prof_keys, static_cast<const double*>(s->prof_vals), s->n_prof);
     XLB_HIP(hipGetLastError());
     return 0;
   });
@@ -943,6 +991,48 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   return 0;
 }
 
+int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const uint32_t* storage_cells, const double* values) {
+  XLB_REQUIRE(s && bc_id >= 1 && bc_id <= 255, "bad argument");
+  XLB_REQUIRE(n == 0 || (storage_cells && values), "null table");
+  xlbhip_ctx* c = s->ctx;
+  XLB_HIP(hipSetDevice(c->device));
+  XLB_HIP(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < n; ++i) s->prof_host[storage_cells[i]] = {values[3 * i], values[3 * i + 1], values[3 * i + 2]};
+  // sorted device image (std::map iterates in key order)
+  std::vector<uint32_t> keys;
+  std::vector<double> v64;
+  keys.reserve(s->prof_host.size());
+  v64.reserve(3 * s->prof_host.size());
+  for (const auto& kv : s->prof_host) {
+    keys.push_back(kv.first);
+    v64.insert(v64.end(), kv.second.begin(), kv.second.end());
+  }
+  if (s->prof_keys) XLB_HIP(hipFree(s->prof_keys));
+  if (s->prof_vals) XLB_HIP(hipFree(s->prof_vals));
+  s->prof_keys = nullptr;
+  s->prof_vals = nullptr;
+  s->n_prof = (int)keys.size();
+  if (s->n_prof > 0) {
+    XLB_HIP(hipMalloc(&s->prof_keys, keys.size() * sizeof(uint32_t)));
+    XLB_HIP(hipMemcpy(s->prof_keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (s->cdt == XLBHIP_F32) {
+      std::vector<float> v32(v64.begin(), v64.end());
+      XLB_HIP(hipMalloc(&s->prof_vals, v32.size() * 4));
+      XLB_HIP(hipMemcpy(s->prof_vals, v32.data(), v32.size() * 4, hipMemcpyHostToDevice));
+    } else {
+      XLB_HIP(hipMalloc(&s->prof_vals, v64.size() * 8));
+      XLB_HIP(hipMemcpy(s->prof_vals, v64.data(), v64.size() * 8, hipMemcpyHostToDevice));
+    }
+  }
+  // flag the BC: its prescribed values come from the table (cell.hpp: PROF_FLAG)
+  const size_t es = s->cdt == XLBHIP_F32 ? 4 : 8;
+  const float one32 = 1.0f;
+  const double one64 = 1.0;
+  XLB_HIP(hipMemcpy(static_cast<char*>(s->tab_values) + ((size_t)bc_id * 27 + PROF_FLAG) * es, es == 4 ? (const void*)&one32 : (const void*)&one64, es,
+                    hipMemcpyHostToDevice));
+  return 0;
+}
+
 int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force) {
   XLB_REQUIRE(s, "stepper is null");
   s->forced = force != nullptr;
@@ -962,6 +1052,8 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   (void)hipStreamSynchronize(s->ctx->stream);
   (void)hipFree(s->tab_kind);
   (void)hipFree(s->tab_values);
+  if (s->prof_keys) (void)hipFree(s->prof_keys);
+  if (s->prof_vals) (void)hipFree(s->prof_vals);
   if (s->meta) (void)hipFree(s->meta);
   if (s->tile_order) (void)hipFree(s->tile_order);
   delete s;

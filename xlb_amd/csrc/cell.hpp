@@ -493,6 +493,22 @@ __device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, co
   });
 }
 
+// ---- per-cell prescribed values (profiles) of Zou-He / Regularized BCs ----
+constexpr int PROF_FLAG = 26;  // slot of the per-BC value vector that says "prescribed values come from the profile table"
+
+// slot of `key` in the sorted table (callers only ask for cells that are in it)
+__device__ __forceinline__ int prof_find(const uint32_t* keys, int n, uint32_t key) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
 constexpr int COLL_FORCED = 4;
 
 struct CollideExtra {

@@ -164,7 +164,7 @@ struct BcValues {
 // bc_fullway_bounce_back.py:52-56, bc_do_nothing.py:50-54
 template <class L, class T>
 __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, FieldView f_post, FieldView bc, FieldView miss,
-                           Dims d) {
+                           Dims d, const uint32_t* prof_keys, const double* prof_vals, int n_prof) {
   int x, y, z;
   if (!cell_of_thread(d, x, y, z)) return;
   const uint8_t b = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
@@ -178,9 +178,11 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
       constexpr int l = decltype(lc)::value;
       ff[l] = load_rt<T>(f_post, (size_t)l * f_post.plane_stride + io);
     });
-    val[0] = static_cast<T>(vals.v[0]);
-    val[1] = static_cast<T>(vals.v[1]);
-    val[2] = static_cast<T>(vals.v[2]);
+    const double* pv = vals.v;
+    if (n_prof > 0) pv = prof_vals + 3 * (size_t)prof_find(prof_keys, n_prof, (uint32_t)cell_index(bc, d, x, y, z));
+    val[0] = static_cast<T>(pv[0]);
+    val[1] = static_cast<T>(pv[1]);
+    val[2] = static_cast<T>(pv[2]);
     zouhe_cell<L, T>(ff, m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
                      kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
     static_for<L::Q>([&](auto lc) {
@@ -274,7 +276,8 @@ __global__ void k_velocity_gradient(FieldView u, FieldView bc, FieldView out_a, 
 // (nse_stepper.py:246-257).  Generic slow path: only the outflow cells and the cells behind them run it.
 template <class L, class T>
 __device__ void post_stream_cell(const FieldView& f0, const FieldView& bc, const FieldView& miss, const Dims& d, const uint8_t* kind_tab,
-                                 const T* val_tab, int x, int y, int z, T (&f)[L::Q]) {
+                                 const T* val_tab, const uint32_t* prof_keys, const T* prof_vals, int n_prof, int x, int y, int z,
+                                 T (&f)[L::Q]) {
   static_for<L::Q>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     const int xs = f0.halo ? x - L::c(0, l) : wrap(x - L::c(0, l), d.nx);
@@ -307,6 +310,7 @@ __device__ void post_stream_cell(const FieldView& f0, const FieldView& bc, const
       f[l] = load_rt<T>(f0, (size_t)l * f0.plane_stride + own);
     });
   } else if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
+    if (val[PROF_FLAG] != T(0) && n_prof > 0) val = prof_vals + 3 * (size_t)prof_find(prof_keys, n_prof, (uint32_t)cell_index(bc, d, x, y, z));
     zouhe_cell<L, T>(f, m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
                      kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
   }
@@ -316,7 +320,8 @@ __device__ void post_stream_cell(const FieldView& f0, const FieldView& bc, const
 // at an outflow cell b with outward normal n, for every direction l whose opposite is missing,
 //   f_1[l](b) = cs * f_post_stream[opp l](b - n) + (1 - cs) * f_post_stream[opp l](b)
 template <class L, class T>
-__global__ void k_outflow_aux(FieldView f0, FieldView f1, FieldView bc, FieldView miss, Dims d, const uint8_t* kind_tab, const T* val_tab) {
+__global__ void k_outflow_aux(FieldView f0, FieldView f1, FieldView bc, FieldView miss, Dims d, const uint8_t* kind_tab, const T* val_tab,
+                              const uint32_t* prof_keys, const T* prof_vals, int n_prof) {
   int x, y, z;
   if (!cell_of_thread(d, x, y, z)) return;
   const unsigned id = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
@@ -332,8 +337,8 @@ __global__ void k_outflow_aux(FieldView f0, FieldView f1, FieldView bc, FieldVie
   }
   const int yn = wrap(y - n1, d.ny), zn = wrap(z - n2, d.nz);
   T fb[L::Q], fn[L::Q];
-  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, x, y, z, fb);
-  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, xn, yn, zn, fn);
+  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, prof_keys, prof_vals, n_prof, x, y, z, fb);
+  post_stream_cell<L, T>(f0, bc, miss, d, kind_tab, val_tab, prof_keys, prof_vals, n_prof, xn, yn, zn, fn);
   const unsigned m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
   const size_t o1 = cell_index(f1, d, x, y, z);
   static_for<L::Q>([&](auto lc) {

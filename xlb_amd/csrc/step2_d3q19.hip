@@ -26,6 +26,9 @@ static int launch2(const StepLaunch& p) {
   a.x_segments = (p.x_segments > 1 && p.x_count >= 8 * p.x_segments) ? p.x_segments : 1;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const float*>(p.tab_values);
+  a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)
+  a.prof_vals = nullptr;
+  a.n_prof = 0;
   a.ids_packed = p.ids_packed;
   a.kinds_packed = p.kinds_packed;
   a.n_bc = p.n_bc;

@@ -30,7 +30,6 @@ namespace xlb {
 // kinds as the kernel sees them
 enum { K_NONE = 0, K_EQ = XLBHIP_BC_EQUILIBRIUM, K_HW = XLBHIP_BC_HALFWAY_BB, K_FW = XLBHIP_BC_FULLWAY_BB, K_DN = XLBHIP_BC_DO_NOTHING };
 constexpr int MAX_FAST_BCS = 8;
-
 template <class T, class S>
 struct StepArgs {
   const S* src;
@@ -42,6 +41,11 @@ struct StepArgs {
   const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
   const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS
+  // per-cell prescribed values of Zou-He / Regularized BCs built with a profile (extended variant only): sorted
+  // storage cell indices and 3 values per entry; a BC uses the table when bc_values[id][PROF_FLAG] != 0
+  const uint32_t* prof_keys;
+  const T* prof_vals;
+  int n_prof;
   unsigned long long ids_packed;  // up to 8 bc ids, one per byte
   unsigned kinds_packed;          // their kinds, one per nibble
   int n_bc;
@@ -324,6 +328,8 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
           } else if (kind >= XLBHIP_BC_ZOUHE_VELOCITY && kind <= XLBHIP_BC_REGULARIZED_PRESSURE) {
             const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
             const T* val = opaque(a.bc_values + id * 27u);
+            if (val[PROF_FLAG] != T(0) && a.n_prof > 0)  // per-cell values (bc_zouhe.py:225-232: the broadcast profile)
+              val = a.prof_vals + 3 * (size_t)prof_find(a.prof_keys, a.n_prof, (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k);
             zouhe_cell<L, T>(f[k], m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
                              kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
           }

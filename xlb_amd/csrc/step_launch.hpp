@@ -16,6 +16,9 @@ struct StepLaunch {
   int x_segments;              // two-step kernel only
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
+  const uint32_t* prof_keys;  // profile table of Zou-He / Regularized BCs (sorted storage cell indices), or nullptr
+  const void* prof_vals;      // compute dtype [n_prof][3]
+  int n_prof;
   unsigned long long ids_packed;
   unsigned kinds_packed;
   int n_bc;
@@ -61,6 +64,9 @@ int launch_typed(const StepLaunch& p) {
   a.x_segments = 1;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const T*>(p.tab_values);
+  a.prof_keys = p.prof_keys;
+  a.prof_vals = static_cast<const T*>(p.prof_vals);
+  a.n_prof = p.n_prof;
   a.ids_packed = p.ids_packed;
   a.kinds_packed = p.kinds_packed;
   a.n_bc = p.n_bc;

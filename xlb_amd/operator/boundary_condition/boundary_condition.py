@@ -44,6 +44,17 @@ class BoundaryConditionRegistry:
 boundary_condition_registry = BoundaryConditionRegistry()
 
 
+class _GridOfField:
+    """What _profile_table needs from a grid, taken from a field (the stand-alone bc(...) call has no grid):
+    single-rank fields only (a slab-decomposed field does not know its x offset)."""
+
+    def __init__(self, field):
+        if field.halo != 0:
+            raise NotImplementedError("the stand-alone call of a profile BC needs fields without ghost planes; use the stepper")
+        self.shape = self.local_shape = field.grid_shape
+        self.x_offset, self.halo = 0, 0
+
+
 class BoundaryCondition(Operator):
     hip_kind = None
 
@@ -89,6 +100,18 @@ class BoundaryCondition(Operator):
 
     def _apply(self, f_pre, f_post, bc_mask, missing_mask):
         desc = self._hip_descriptor()
+        if getattr(self, "prescribed_values", None) is not None:
+            keys, vals = self._profile_table(_GridOfField(f_post))
+            keys = np.ascontiguousarray(keys, dtype=np.uint32)
+            vals = np.ascontiguousarray(vals, dtype=np.float64)
+            _lib.check(
+                _lib.load().xlbhip_apply_bc_profile(
+                    self._ctx.handle, self.velocity_set.hip_id, self._compute_code, _lib.C.byref(desc), f_pre.handle, f_post.handle,
+                    bc_mask.handle, missing_mask.handle if missing_mask is not None else None, int(keys.shape[0]), keys.ctypes.data,
+                    vals.ctypes.data,
+                )
+            )
+            return f_post
         import ctypes
 
         _lib.check(
@@ -209,8 +232,14 @@ class DoNothingBC(BoundaryCondition):
 class ZouHeBC(BoundaryCondition):
     """Zou-He inlet / outlet: non-equilibrium bounce-back of the missing populations around
     feq(rho, u) with either the normal velocity or the density prescribed
-    (reference xlb/operator/boundary_condition/bc_zouhe.py:37-304, JAX semantics: a CONSTANT
-    ``prescribed_value`` lives in the BC object; callable profiles are out of scope here)."""
+    (reference xlb/operator/boundary_condition/bc_zouhe.py:37-304, JAX semantics).
+
+    ``prescribed_value``: a constant velocity vector / density.  ``profile``: a callable WITHOUT arguments returning an
+    array ``(d, ...)`` (velocity) or ``(1, ...)`` (density) that is broadcast over the grid the way the JAX branch does
+    (``_broadcast_prescribed_values``, bc_zouhe.py:179-214: missing axes are inserted after the first one, e.g. a
+    ``(3, ny, nz)`` inlet profile applies to every x); NumPy instead of jax.numpy.  The values at this BC's cells go to
+    the stepper as a sparse per-cell table (``xlbhip_stepper_set_bc_profile``) — the role the aux-data encoding in
+    ``f_1`` plays for the reference's kernel backends."""
 
     _kinds = {"velocity": _lib.BC_ZOUHE_VELOCITY, "pressure": _lib.BC_ZOUHE_PRESSURE}
 
@@ -221,10 +250,23 @@ class ZouHeBC(BoundaryCondition):
         super().__init__(ImplementationStep.STREAMING, velocity_set, precision_policy, compute_backend, indices, mesh_vertices,
                          voxelization_method)
         self.hip_kind = self._kinds[bc_type]
+        self.profile = profile
+        self.prescribed_values = None
         if profile is not None:
             if prescribed_value is not None:
                 raise ValueError("Cannot specify both profile and prescribed_value")
-            raise NotImplementedError("callable profiles are out of scope of the HIP backend; use prescribed_value")
+            if not callable(profile):
+                raise ValueError("profile must be a callable returning an array")
+            self.prescribed_values = np.asarray(profile(), dtype=np.float64)  # bc_zouhe.py:122-124
+            lead = self.velocity_set.d if bc_type == "velocity" else 1
+            if self.prescribed_values.ndim < 1 or self.prescribed_values.shape[0] != lead:
+                raise ValueError(f"profile() must return an array whose first axis has {lead} component(s)")
+            self.prescribed_value = None
+            self.needs_padding = True
+            if indices is None:
+                raise ValueError("a profile BC needs indices (its per-cell values are evaluated there)")
+            self._profile_cells = np.array(indices, dtype=np.int64)  # the masker drops bc.indices once the masks exist
+            return
         if prescribed_value is None:
             raise ValueError("prescribed_value is required")
         if bc_type == "velocity":
@@ -242,9 +284,53 @@ class ZouHeBC(BoundaryCondition):
         self.prescribed_value = prescribed_value
         self.needs_padding = True
 
+    def _values_at(self, cells, grid_shape):
+        """The broadcast profile evaluated at ``cells`` ((d, n) global indices) -> (n, 3) values in the internal
+        3-component form, rounded to the store precision first like a constant value (bc_zouhe.py:155-156)."""
+        pv = self.prescribed_values
+        d = self.velocity_set.d
+        nd_target = d + 1
+        if pv.ndim > nd_target:
+            raise ValueError("prescribed_values has more dimensions than target_shape")
+        if pv.ndim < nd_target:  # bc_zouhe.py:195-204: singleton axes go right after the first one
+            pv = pv.reshape((pv.shape[0],) + (1,) * (nd_target - pv.ndim) + pv.shape[1:])
+        for pd, td in zip(pv.shape[1:], grid_shape):
+            if pd != 1 and pd != td:
+                raise ValueError(f"Cannot broadcast dimension {pd} to {td}")
+        idx = tuple(np.zeros_like(cells[a]) if pv.shape[1 + a] == 1 else cells[a] for a in range(d))
+        vals = pv[(slice(None),) + idx]  # (lead, n)
+        S = self.store_dtype
+        vals = vals.astype(S).astype(np.float64)
+        out = np.zeros((cells.shape[1], 3))
+        if self.bc_type == "velocity":
+            out[:, 3 - d :] = vals.T
+        else:
+            out[:, 0] = vals[0]
+        return out
+
+    def _profile_table(self, grid):
+        """(storage cell indices, (n, 3) values) of this BC's cells on this rank — None for constant values."""
+        if self.prescribed_values is None:
+            return None
+        cells = self._profile_cells
+        d = self.velocity_set.d
+        x0 = getattr(grid, "x_offset", 0)
+        local = getattr(grid, "local_shape", grid.shape)
+        halo = getattr(grid, "halo", 0)
+        keep = (cells[0] >= x0) & (cells[0] < x0 + local[0])
+        cells = cells[:, keep]
+        vals = self._values_at(cells, grid.shape)
+        s3 = (1,) + tuple(local) if d == 2 else tuple(local)
+        c3 = np.vstack([np.zeros((1, cells.shape[1]), np.int64), cells]) if d == 2 else cells.copy()
+        c3[0] = c3[0] - (x0 if d == 3 else 0) + halo
+        keys = (c3[0] * s3[1] + c3[1]) * s3[2] + c3[2]
+        return keys.astype(np.uint32), vals
+
     def _hip_values(self):
         S = self.store_dtype
         out = np.zeros(27)
+        if self.prescribed_values is not None:
+            return out  # per-cell values: see _profile_table
         if self.bc_type == "velocity":
             v = self.prescribed_value.astype(S).astype(np.float64)  # bc_zouhe.py:155-156: store precision first
             out[3 - self.velocity_set.d : 3] = v  # internal 3-component form

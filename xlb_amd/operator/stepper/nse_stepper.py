@@ -71,6 +71,10 @@ class IncompressibleNavierStokesStepper(Stepper):
                                         self._store_code, descs)
             if isinstance(self.collision, SmagorinskyLESBGK):
                 self._native.set_smagorinsky(self.collision.smagorinsky_coef)
+            for bc in self.boundary_conditions:
+                table = bc._profile_table(self.grid) if hasattr(bc, "_profile_table") else None
+                if table is not None:
+                    self._native.set_bc_profile(bc.id, *table)
             if self.force_vector is not None:
                 f3 = np.zeros(3)
                 f3[3 - self.velocity_set.d :] = self.force_vector  # internal 3-component form
