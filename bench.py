@@ -125,7 +125,10 @@ def main():
     from xlb_amd.operator.boundary_condition import EquilibriumBC, FullwayBounceBackBC, HalfwayBounceBackBC
     from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
 
-    rank, world = xdist.init_process_group()
+    # XLB_BENCH_TRANSPORT=host: rehearsal of the N > 1 code path with all ranks on ONE GPU (ghost planes through gloo;
+    # RCCL refuses two ranks on a device).  Numbers from it are not benchmark results.
+    transport = os.environ.get("XLB_BENCH_TRANSPORT", "rccl")
+    rank, world = xdist.init_process_group(transport=transport)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run --nproc-per-node {args.gpus}")
 
@@ -216,7 +219,8 @@ def main():
             "workload": f"{args.lattice} {args.collision} {args.policy} {args.workload} {shape[0]}x{n}x{n} ({n}^3 per GPU), omega=1.0",
             "baseline_config": "configs[2]" if (args.workload == "cavity_halfway" and n == 512 and world == 1) else
                                ("configs[3] (long axis = slowest array axis)" if (n == 512 and world == 8) else "other"),
-            "decomposition": f"{world} x-slab(s), ring halo over RCCL" if world > 1 else "single GPU",
+            "decomposition": (f"{world} x-slab(s), ring halo over RCCL" if transport == "rccl" else
+                              f"{world} x-slab(s), REHEARSAL transport {transport}") if world > 1 else "single GPU",
         },
         "roofline": {
             "bound": "hbm",
