@@ -19,6 +19,7 @@ import xlb_amd as xlb
 from xlb_amd import ComputeBackend, PrecisionPolicy
 from xlb_amd.grid import grid_factory
 from xlb_amd.operator.boundary_condition import ExtrapolationOutflowBC, FullwayBounceBackBC, HalfwayBounceBackBC, RegularizedBC
+from xlb_amd.operator.force import MomentumTransfer
 from xlb_amd.operator.macroscopic import Macroscopic
 from xlb_amd.operator.postprocess import QCriterion, Vorticity
 from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
@@ -80,6 +81,9 @@ u = grid.create_field(3, dtype=Precision.FP32)
 Macroscopic()(f_0, rho, u)
 vort, mag = Vorticity()(u, bc_mask, grid.create_field(3, dtype=Precision.FP32), grid.create_field(1, dtype=Precision.FP32))
 _, q = QCriterion()(u, bc_mask, grid.create_field(1, dtype=Precision.FP32), grid.create_field(1, dtype=Precision.FP32))
+force = MomentumTransfer(bc_sphere)(f_0, f_1, bc_mask, missing_mask)
+cd = 2.0 * force[0] / (1.0 * (2.0 / 3.0 * args.u_max) ** 2 * np.pi * radius**2)  # mean of the parabolic profile ~ 2/3 u_max ... rough
+print(f"force on the sphere {force}, drag coefficient (rough, channel-confined) {cd:.2f}")
 un, rn, mn, qn = u.numpy(), rho.numpy(), mag.numpy(), q.numpy()
 fluid = bc_mask.numpy()[0] == 0
 print(f"rho in [{rn[0][fluid].min():.4f}, {rn[0][fluid].max():.4f}], max |u| {np.sqrt((un**2).sum(0))[fluid].max():.4f}, "

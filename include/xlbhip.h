@@ -138,6 +138,12 @@ int xlbhip_second_moment(xlbhip_ctx* ctx, int lattice, int compute_dtype, const 
 int xlbhip_apply_bc_profile(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_bc_desc* bc, const xlbhip_field* f_pre,
                             xlbhip_field* f_post, const xlbhip_field* bc_mask, const xlbhip_field* missing_mask, int64_t n,
                             const uint32_t* storage_cells, const double* values);
+/* MomentumTransfer(no_slip_bc)(f_0, f_1, bc_mask, missing_mask) -> net force on the solid behind the BC
+ * (force/momentum_transfer.py:167-205, JAX; f_0 = post-collision populations, i.e. the field a step returned).
+ * The BC must be a halfway or fullway bounce-back; force_out = (F_x, F_y, F_z) in the internal 3-component form,
+ * the sum over THIS rank's cells (slab runs add the ranks' vectors).  Synchronous. */
+int xlbhip_momentum_transfer(xlbhip_ctx* ctx, int lattice, int compute_dtype, const xlbhip_bc_desc* no_slip_bc, const xlbhip_field* f_0,
+                             const xlbhip_field* bc_mask, const xlbhip_field* missing_mask, double force_out[3]);
 /* Vorticity()(u, bc_mask, vorticity, vorticity_magnitude): postprocess/vorticity.py:30-93 (3-D; cells one layer inside the
  * box whose six face neighbours are all fluid get the curl of u by central differences and its magnitude; every other cell of
  * the outputs is left untouched).  Arithmetic in u's dtype (fp32 / fp64). */

@@ -685,3 +685,20 @@ def q_criterion(u, bc_mask, norm_mu, q):
     q[0][c] = np.where(ok, qv, q[0][c])
     return norm_mu, q
 
+
+def momentum_transfer(f_0, bc, bc_mask, missing_mask, lat, policy="FP32FP32"):
+    """MomentumTransfer.jax_implementation, force/momentum_transfer.py:167-205 (stream-then-collide): f_0 = post-collision.
+    Returns the net force (d,) in the compute dtype; the reduction order over the grid is NumPy's (the reference's is
+    XLA's: unpinned), so callers compare with a tolerance."""
+    T = compute_dtype(policy)
+    f_pc = f_0.astype(T)
+    f_ps = stream(f_pc, lat)
+    f_ps = apply_bc(bc, f_pc, f_ps, bc_mask, missing_mask, lat, policy)
+    mm = missing_mask.astype(bool)
+    boundary = _bcast(bc_mask == bc.id, lat.q)
+    is_edge = np.logical_and(boundary, ~mm[0])
+    phi = f_pc[lat.opp] + f_ps
+    phi = np.where(np.logical_and(mm, is_edge), phi, T(0.0))
+    force = np.tensordot(lat.c[:, lat.opp].astype(T), phi, axes=(-1, 0))
+    return force.reshape(lat.d, -1).sum(axis=1, dtype=np.float64).astype(T)
+

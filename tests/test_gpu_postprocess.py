@@ -118,3 +118,44 @@ def test_zero_copy_export_to_torch():
     out = subprocess.run([sys.executable, os.path.join(root, "tests", "_gpu_dlpack_worker.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DLPACK_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
 
+
+
+@pytest.mark.parametrize("policy", ["FP32FP32", "FP64FP64"])
+def test_momentum_transfer_on_a_sphere(policy):
+    """MomentumTransfer(no_slip_bc)(f_0, f_1, bc_mask, missing_mask) on a halfway sphere in a driven channel, against the
+    oracle's restatement of force/momentum_transfer.py:167-205.  The per-cell terms are the same arithmetic; the grid sum
+    is accumulated in double on the device (the reference's order is XLA's), hence a tolerance instead of bit-equality."""
+    from xlb_amd.grid import grid_factory
+    from xlb_amd.operator.boundary_condition import FullwayBounceBackBC, RegularizedBC
+    from xlb_amd.operator.force import MomentumTransfer
+
+    shape = (24, 12, 12)
+    vs, pp = init_hip("D3Q19", policy)
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    walls = [sum((box[f][i] for f in ("bottom", "top", "front", "back")), []) for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    x, y, z = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    sphere = [s.tolist() for s in np.where((x - 8) ** 2 + (y - 6) ** 2 + (z - 6) ** 2 < 2.6**2)]
+    b_w = FullwayBounceBackBC(indices=walls)
+    b_in = RegularizedBC("velocity", prescribed_value=(0.04, 0.0, 0.0), indices=box_ne["left"])
+    b_out = RegularizedBC("pressure", prescribed_value=1.0, indices=box_ne["right"])
+    b_s = HalfwayBounceBackBC(indices=sphere)
+    obcs = [orc.BC(orc.KIND_FULLWAY_BB, b_w.id, walls), orc.BC(orc.KIND_REGULARIZED_VELOCITY, b_in.id, box_ne["left"], prescribed=(0.04, 0.0, 0.0)),
+            orc.BC(orc.KIND_REGULARIZED_PRESSURE, b_out.id, box_ne["right"], prescribed=1.0), orc.BC(orc.KIND_HALFWAY_BB, b_s.id, sphere)]
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_w, b_in, b_out, b_s])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.4, 60)
+    force = MomentumTransfer(b_s)(f_0, f_1, bc_mask, missing_mask)
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    exp = orc.momentum_transfer(f_0.numpy(), obcs[3], o_bm, o_mm, lat, policy)
+    assert force.shape == (3,) and force.dtype == orc.compute_dtype(policy)
+    tol = 1e-5 if policy == "FP32FP32" else 1e-12
+    assert np.allclose(force, exp, rtol=tol, atol=tol * np.abs(exp).max()), (force, exp)
+    assert force[0] > 0 and abs(force[1]) < 0.05 * force[0] and abs(force[2]) < 0.05 * force[0]  # drag along the flow, no net lift
+    # a fullway no-slip BC goes through the same operator (f_post_stream[l] = f_0[opp l])
+    fw = MomentumTransfer(b_w)(f_0, f_1, bc_mask, missing_mask)
+    exp_fw = orc.momentum_transfer(f_0.numpy(), obcs[0], o_bm, o_mm, lat, policy)
+    assert np.allclose(fw, exp_fw, rtol=10 * tol, atol=10 * tol * np.abs(exp_fw).max()), (fw, exp_fw)

@@ -455,6 +455,45 @@ int xlbhip_macroscopic(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_field* 
   });
 }
 
+int xlbhip_momentum_transfer(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc_desc* bc, const xlbhip_field* f_0, const xlbhip_field* bcm,
+                             const xlbhip_field* miss, double force_out[3]) {
+  XLB_REQUIRE(c && bc && force_out, "null argument");
+  XLB_CHECK_POP(f_0, lattice, "momentum_transfer(f_0)");
+  XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_0) && bcm->halo == f_0->halo, "momentum_transfer: bad bc_mask field");
+  XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_0) && miss->halo == f_0->halo, "momentum_transfer: needs the missing_mask field");
+  XLB_REQUIRE(bc->kind == XLBHIP_BC_HALFWAY_BB || bc->kind == XLBHIP_BC_FULLWAY_BB,
+              "momentum_transfer: the no-slip BC must be a halfway or fullway bounce-back (kind %d given)", bc->kind);
+  XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
+  BcValues vals;
+  std::memcpy(vals.v, bc->values, sizeof(vals.v));
+  double* dforce = nullptr;
+  XLB_HIP(hipMalloc(&dforce, 3 * sizeof(double)));
+  XLB_HIP(hipMemsetAsync(dforce, 0, 3 * sizeof(double), c->stream));
+  const size_t n = f_0->cells();
+  const int wall = bc->kind == XLBHIP_BC_HALFWAY_BB ? 1 : 0;
+  int rc = by_lattice(lattice, [&](auto L) {
+    using LL = decltype(L);
+    if (cdt == XLBHIP_F32)
+      hipLaunchKernelGGL((k_momentum_transfer<LL, float>), blocks_for(n), 256, 0, c->stream, view(f_0), view(bcm), view(miss), dims(f_0), bc->id, vals,
+                         wall, dforce);
+    else
+      hipLaunchKernelGGL((k_momentum_transfer<LL, double>), blocks_for(n), 256, 0, c->stream, view(f_0), view(bcm), view(miss), dims(f_0), bc->id, vals,
+                         wall, dforce);
+    XLB_HIP(hipGetLastError());
+    return 0;
+  });
+  if (rc == 0) {
+    hipError_t e = hipMemcpyAsync(force_out, dforce, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(dforce);
+      XLB_FAIL("momentum_transfer: %s", hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(dforce);
+  return rc;
+}
+
 int xlbhip_vorticity(xlbhip_ctx* c, const xlbhip_field* u, const xlbhip_field* bcm, xlbhip_field* vorticity, xlbhip_field* magnitude) {
   return velocity_gradient_launch<0>(c, u, bcm, vorticity, magnitude, "vorticity");
 }

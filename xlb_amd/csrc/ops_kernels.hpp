@@ -271,6 +271,59 @@ __global__ void k_velocity_gradient(FieldView u, FieldView bc, FieldView out_a, 
   }
 }
 
+// ---- MomentumTransfer (force/momentum_transfer.py:167-205, JAX): force on the solid behind a no-slip BC ----------
+// f0 holds post-collision populations.  At every cell of the BC that is not itself solid (rest direction not
+// missing), for every missing direction l:  phi_l = f0[opp l] + f_post_stream[l],  f_post_stream[l] = the BC's
+// bounce-back of the own cell (halfway: f0[opp l] + wall term; fullway: f0[opp l]);  F = sum c_{opp l} phi_l.
+// One double-precision atomic per block and component (the grid sum's order is unpinned in the reference as well).
+template <class L, class T>
+__global__ void k_momentum_transfer(FieldView f0, FieldView bc, FieldView miss, Dims d, int id, BcValues vals, int add_wall_term,
+                                    double* force /*[3]*/) {
+  __shared__ double red[3][256];
+  int x, y, z;
+  T fx = T(0), fy = T(0), fz = T(0);
+  if (cell_of_thread(d, x, y, z)) {
+    const uint8_t b = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+    if (b == id) {
+      const unsigned m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+      if ((m & 1u) == 0u) {  // is_edge: boundary & ~missing_mask[0]
+        const size_t own = cell_index(f0, d, x, y, z);
+        static_for<L::Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int o = opp<L>(l);
+          if ((m >> l) & 1u) {
+            const T fo = load_rt<T>(f0, (size_t)o * f0.plane_stride + own);
+            T ps = fo;
+            if (add_wall_term) ps = fo + static_cast<T>(vals.v[l]);
+            const T phi = fo + ps;
+            // force += c[:, opp l] * phi
+            if constexpr (L::c(0, o) == 1) fx = fx + phi;
+            if constexpr (L::c(0, o) == -1) fx = fx - phi;
+            if constexpr (L::c(1, o) == 1) fy = fy + phi;
+            if constexpr (L::c(1, o) == -1) fy = fy - phi;
+            if constexpr (L::c(2, o) == 1) fz = fz + phi;
+            if constexpr (L::c(2, o) == -1) fz = fz - phi;
+          }
+        });
+      }
+    }
+  }
+  const int t = threadIdx.x;
+  red[0][t] = (double)fx;
+  red[1][t] = (double)fy;
+  red[2][t] = (double)fz;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      red[0][t] += red[0][t + s];
+      red[1][t] += red[1][t + s];
+      red[2][t] += red[2][t + s];
+    }
+    __syncthreads();
+  }
+  if (t < 3 && red[t][0] != 0.0) atomicAdd(force + t, red[t][0]);
+}
+
 // ---- ExtrapolationOutflowBC: auxiliary data after the collision --------------------------
 // Post-stream populations of ONE cell: periodic pull + the STREAMING-step boundary condition of that cell
 // (nse_stepper.py:246-257).  Generic slow path: only the outflow cells and the cells behind them run it.
