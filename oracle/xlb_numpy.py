@@ -702,3 +702,26 @@ def momentum_transfer(f_0, bc, bc_mask, missing_mask, lat, policy="FP32FP32"):
     force = np.tensordot(lat.c[:, lat.opp].astype(T), phi, axes=(-1, 0))
     return force.reshape(lat.d, -1).sum(axis=1, dtype=np.float64).astype(T)
 
+
+def sphere_channel(shape=(28, 14, 14), u_max=0.04, inlet_kind=KIND_REGULARIZED_VELOCITY):
+    """The boundary-condition set of examples/cfd/flow_past_sphere_3d.py:104-112 on a small box: fullway walls (id 1), a
+    velocity inlet with a parabolic PROFILE (id 2), extrapolation outflow (id 3), a halfway sphere from interior indices
+    (id 4) — ids in the example's construction order.  Returns (lattice, bcs, profile array (3, ny, nz))."""
+    lat = Lattice("D3Q19")
+    box = bounding_box_indices(shape)
+    box_ne = bounding_box_indices(shape, remove_edges=True)
+    walls = [sum((list(box[f][i]) for f in ("bottom", "top", "front", "back")), []) for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1)
+    ny, nz = shape[1], shape[2]
+    y, z = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+    hy, hz = ny - 1.0, nz - 1.0
+    r2 = (2.0 * (y - hy / 2.0) / hy) ** 2 + (2.0 * (z - hz / 2.0) / hz) ** 2
+    ux = u_max * np.maximum(0.0, 1.0 - r2)
+    prof = np.stack([ux, np.zeros_like(ux), np.zeros_like(ux)])
+    x, y, z = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    r = 0.23 * shape[1]
+    sphere = np.array(np.where((x - shape[0] // 3) ** 2 + (y - shape[1] // 2) ** 2 + (z - shape[2] // 2) ** 2 < r * r))
+    bcs = [BC(KIND_FULLWAY_BB, 1, walls), BC(inlet_kind, 2, box_ne["left"], prescribed=prof), BC(KIND_EXTRAPOLATION_OUTFLOW, 3, box_ne["right"]),
+           BC(KIND_HALFWAY_BB, 4, sphere)]
+    return lat, bcs, prof
+

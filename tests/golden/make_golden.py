@@ -91,6 +91,22 @@ def d2q9_kbc(n=16, steps=20):
     save(f"d2q9_kbc_cavity_{n}", steps=np.int64(steps), omega=np.float64(1.6), f=f)
 
 
+def sphere_channel(steps=30):
+    """flow past a sphere: populations, vorticity magnitude / Q of the velocity field and
+    the momentum-exchange force on the sphere"""
+    shape = (28, 14, 14)
+    lat, bcs, _ = orc.sphere_channel(shape)
+    bc_mask, missing = orc.build_masks(shape, lat, bcs)
+    with np.errstate(all="ignore"):
+        f = orc.run(orc.initialize_eq(shape, lat), bc_mask, missing, bcs, 1.5, lat, steps)
+    rho, u = macro(f, lat, "FP32FP32")
+    zero = np.zeros((3,) + shape, np.float32)
+    vort, mag = orc.vorticity(u, bc_mask, zero, zero[:1])
+    _, q = orc.q_criterion(u, bc_mask, zero[:1], zero[:1])
+    force = orc.momentum_transfer(f, bcs[3], bc_mask, missing, lat)
+    save("d3q19_sphere_channel", steps=np.int64(steps), omega=np.float64(1.5), f=f, bc_mask=bc_mask, vorticity_magnitude=mag, q=q, force=force)
+
+
 if __name__ == "__main__":
     cavity_2d(16, [1, 10, 100])
     cavity_2d(128, [1, 10, 100, 1000])
@@ -98,3 +114,4 @@ if __name__ == "__main__":
     d3q19_cavity()
     d3q27_kbc()
     d2q9_kbc()
+    sphere_channel()

@@ -265,3 +265,36 @@ def test_pressure_profile_and_errors():
         ZouHeBC("velocity", profile=lambda: rho_face, prescribed_value=(0.1, 0, 0), indices=box_ne["left"])
     with pytest.raises(ValueError, match="first axis"):
         ZouHeBC("velocity", profile=lambda: rho_face, indices=box_ne["left"])
+
+
+def test_flow_past_sphere_vs_golden():
+    """HIP backend against the committed vectors of tests/golden/d3q19_sphere_channel.npz: populations bit-exact, vorticity
+    magnitude / Q bit-exact, force to rounding."""
+    from _util import golden
+    from xlb_amd.operator.force import MomentumTransfer
+    from xlb_amd.operator.macroscopic import Macroscopic
+    from xlb_amd.operator.postprocess import QCriterion, Vorticity
+    from xlb_amd.precision_policy import Precision
+
+    g = golden("d3q19_sphere_channel")
+    shape = (28, 14, 14)
+    vs, pp = init_hip("D3Q19")
+    lat, obcs, prof = orc.sphere_channel(shape)
+    grid = grid_factory(shape)
+    b_w = FullwayBounceBackBC(indices=obcs[0].indices.tolist())
+    b_in = RegularizedBC("velocity", profile=lambda: prof, indices=obcs[1].indices.tolist())
+    b_out = ExtrapolationOutflowBC(indices=obcs[2].indices.tolist())
+    b_s = HalfwayBounceBackBC(indices=obcs[3].indices.tolist())
+    assert [b.id for b in (b_w, b_in, b_out, b_s)] == [1, 2, 3, 4]
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_w, b_in, b_out, b_s])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert np.array_equal(bc_mask.numpy(), g["bc_mask"])
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, float(g["omega"]), int(g["steps"]))
+    assert np.array_equal(f_0.numpy(), g["f"])
+    rho, u = grid.create_field(1, dtype=Precision.FP32), grid.create_field(3, dtype=Precision.FP32)
+    Macroscopic()(f_0, rho, u)
+    _, mag = Vorticity()(u, bc_mask, grid.create_field(3, dtype=Precision.FP32), grid.create_field(1, dtype=Precision.FP32))
+    _, q = QCriterion()(u, bc_mask, grid.create_field(1, dtype=Precision.FP32), grid.create_field(1, dtype=Precision.FP32))
+    assert np.array_equal(mag.numpy(), g["vorticity_magnitude"]) and np.array_equal(q.numpy(), g["q"])
+    force = MomentumTransfer(b_s)(f_0, f_1, bc_mask, missing_mask)
+    assert np.allclose(force, g["force"], rtol=1e-5, atol=1e-5 * np.abs(g["force"]).max())

@@ -101,3 +101,25 @@ def test_outflow_auxiliary_data_matches_per_cell_restatement():
     # every other BC kind leaves the post-collision populations alone (boundary_condition.py:138-144)
     wall = orc.BC(orc.KIND_HALFWAY_BB, 5, box["bottom"])
     assert orc.assemble_auxiliary_data(wall, ps, pc, bm, mm, lat) is pc
+
+
+def test_sphere_channel_golden_pins_the_oracle():
+    """The widened rows (profile inlet, extrapolation outflow, interior halfway sphere, vorticity / Q, momentum exchange)
+    have no reference test: the committed vectors pin the oracle's restatement of them against later edits."""
+    from oracle import xlb_numpy as orc
+
+    g = np.load(os.path.join(GOLDEN, "d3q19_sphere_channel.npz"))
+    shape = (28, 14, 14)
+    lat, bcs, prof = orc.sphere_channel(shape)
+    assert prof.shape == (3, 14, 14) and [b.id for b in bcs] == [1, 2, 3, 4] and bcs[2].normal.tolist() == [1, 0, 0]
+    bc_mask, missing = orc.build_masks(shape, lat, bcs)
+    assert np.array_equal(bc_mask, g["bc_mask"])
+    with np.errstate(all="ignore"):
+        f = orc.run(orc.initialize_eq(shape, lat), bc_mask, missing, bcs, float(g["omega"]), lat, int(g["steps"]))
+    assert np.array_equal(f, g["f"])
+    rho, u = orc.macroscopic(f, lat)
+    zero = np.zeros((3,) + shape, np.float32)
+    assert np.array_equal(orc.vorticity(u, bc_mask, zero, zero[:1])[1], g["vorticity_magnitude"])
+    assert np.array_equal(orc.q_criterion(u, bc_mask, zero[:1], zero[:1])[1], g["q"])
+    assert np.array_equal(orc.momentum_transfer(f, bcs[3], bc_mask, missing, lat), g["force"])
+    assert g["force"][0] > 0  # drag
