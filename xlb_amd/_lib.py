@@ -101,6 +101,9 @@ def load():
             f"{LIB_PATH} not found: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "xlb_amd has no CPU fallback."
         )
+    # Multi-process runs share device memory through dmabuf IPC on this driver stack; the HIP runtime reads the switch
+    # when it initialises, i.e. with the first call into the library (RCCL: "hipIpcGetMemHandle: invalid argument" otherwise)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
