@@ -199,7 +199,7 @@ def main():
         return
     # xlbhip_run fuses two steps per launch where the library's rule says so (D3Q19 BGK fp32, basic BCs,
     # ny % 8 == nz % 64 == 0, enough tile segments to fill the chip): ask it, to name the kernel that actually ran
-    fused2 = args.steps >= 4 and stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    fused2 = args.steps >= 2 and stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
     kernel = (f"k_step2<{args.lattice}, {args.collision}, {args.policy}> (two steps per launch through LDS)" if fused2 else
               f"k_step<{args.lattice}, {args.collision}, {args.policy}, vec{ctx.get_option('vec') or 1}>")
     out = {

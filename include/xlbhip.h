@@ -203,10 +203,15 @@ int xlbhip_step2_eligible(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_f
                           const xlbhip_field* missing_mask);
 int xlbhip_step2(xlbhip_stepper* s, const xlbhip_field* f_src, xlbhip_field* f_dst, const xlbhip_field* bc_mask,
                  const xlbhip_field* missing_mask, double omega, int64_t timestep);
-/* as xlbhip_run, bracketed by HIP events on the compute stream; returns device ms for the whole loop */
+/* as xlbhip_run without the placement contract: every pair of steps may be fused (xlbhip_run keeps an even number of fused
+ * passes and finishes with single steps to honour its contract); *result_in_b = 1 when the result is in f_b */
+int xlbhip_run_any(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
+                   const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps, int* result_in_b);
+/* the same loop bracketed by HIP events on the compute stream; returns device ms for the whole loop.
+ * result_in_b == NULL: xlbhip_run's placement; otherwise as xlbhip_run_any */
 int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* f_a, xlbhip_field* f_b, const xlbhip_field* bc_mask,
                      const xlbhip_field* missing_mask, double omega, int64_t first_timestep, int64_t n_steps,
-                     float* device_ms);
+                     float* device_ms, int* result_in_b);
 
 /* ---- slab decomposition over ranks (one process per GPU) ------------------ */
 /* semantics reference: xlb/distribute/distribute.py:18-48 (ring exchange of the

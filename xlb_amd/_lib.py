@@ -78,7 +78,8 @@ SIGNATURES = {
     "xlbhip_stepper_set_smagorinsky": [_p, _d],
     "xlbhip_step": [_p, _p, _p, _p, _p, _d, _i64],
     "xlbhip_run": [_p, _p, _p, _p, _p, _d, _i64, _i64],
-    "xlbhip_run_timed": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_float)],
+    "xlbhip_run_timed": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_float), C.POINTER(C.c_int)],
+    "xlbhip_run_any": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_int)],
     "xlbhip_comm_unique_id": [_p],
     "xlbhip_comm_init": [_p, _i, _i, _p, _i],
     "xlbhip_comm_destroy": [_p],
@@ -439,14 +440,18 @@ class Stepper:
         check(load().xlbhip_step2(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
 
     def run(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
-        check(load().xlbhip_run(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
-                                int(n_steps)))
+        """n steps; returns True when the result is in f_b (every pair of steps fused where the kernel exists)."""
+        where = C.c_int()
+        check(load().xlbhip_run_any(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
+                                    int(n_steps), C.byref(where)))
+        return bool(where.value)
 
     def run_timed(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
-        ms = C.c_float()
+        """As run(); returns (result is in f_b, device milliseconds)."""
+        ms, where = C.c_float(), C.c_int()
         check(load().xlbhip_run_timed(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
-                                      int(n_steps), C.byref(ms)))
-        return ms.value
+                                      int(n_steps), C.byref(ms), C.byref(where)))
+        return bool(where.value), ms.value
 
     def free(self):
         if self._h:

@@ -1106,14 +1106,14 @@ int xlbhip_step(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, c
   return step_once(s, src, dst, bcm, miss, omega);
 }
 
-int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
-               int64_t t0, int64_t n) {
-  (void)t0;
+// n steps; `fixed_placement`: the result must land in f_a for even n and in f_b for odd n (xlbhip_run's contract);
+// otherwise every pair of steps is fused and *result_in_b reports where the result is (xlbhip_run_any)
+static int run_steps(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
+                     int64_t n, bool fixed_placement, int* result_in_b) {
   XLB_REQUIRE(n >= 0, "n_steps < 0");
   if (int rc = check_step_fields(s, a, b, bcm, miss)) return rc;
-  // Result placement contract: f_a if n is even, else f_b.  With two-step fusion ("fuse2") a pair of
-  // steps is ONE pass a -> b; to keep the contract, pairs alternate direction (a -> b, b -> a, ...), and a
-  // trailing half pair (buffer parity) is fixed up by single steps.
+  // With two-step fusion ("fuse2") a pair of steps is ONE pass a -> b: pairs alternate direction (a -> b, b -> a, ...).
+  // Under the fixed placement contract a trailing half pair (buffer parity) is fixed up by single steps.
   int64_t i = 0;
   xlbhip_field* cur = a;
   xlbhip_field* oth = b;
@@ -1124,8 +1124,7 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
     // choose the number of pairs so that the remaining single steps land the result in the right buffer:
     // after P pairs the data sits in (P odd ? b : a); then r = n - 2P single steps flip r more times.
     // P + r must be congruent to n (mod 2)  <=>  P even.  Use the largest even P with 2P <= n.
-    int64_t pairs = (n / 2) & ~int64_t(1);
-    if (pairs == 0 && n >= 2) pairs = 0;
+    int64_t pairs = fixed_placement ? ((n / 2) & ~int64_t(1)) : n / 2;
     for (int64_t k = 0; k < pairs; ++k) {
       if (int rc = step_twice(s, cur, oth, bcm, miss, omega)) return rc;
       xlbhip_field* tmp = cur;
@@ -1140,7 +1139,21 @@ int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip
     cur = oth;
     oth = tmp;
   }
+  if (result_in_b) *result_in_b = cur == b ? 1 : 0;
   return 0;
+}
+
+int xlbhip_run(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
+               int64_t t0, int64_t n) {
+  (void)t0;
+  return run_steps(s, a, b, bcm, miss, omega, n, true, nullptr);
+}
+
+int xlbhip_run_any(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
+                   int64_t t0, int64_t n, int* result_in_b) {
+  (void)t0;
+  XLB_REQUIRE(result_in_b, "result_in_b is null");
+  return run_steps(s, a, b, bcm, miss, omega, n, false, result_in_b);
 }
 
 int xlbhip_step2_eligible(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
@@ -1158,11 +1171,12 @@ int xlbhip_step2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, 
 }
 
 int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const xlbhip_field* bcm, const xlbhip_field* miss, double omega,
-                     int64_t t0, int64_t n, float* ms) {
+                     int64_t t0, int64_t n, float* ms, int* result_in_b) {
   XLB_REQUIRE(s && ms, "null argument");
   xlbhip_ctx* c = s->ctx;
   XLB_HIP(hipEventRecord(c->ev_a, c->stream));
-  if (int rc = xlbhip_run(s, a, b, bcm, miss, omega, t0, n)) return rc;
+  // (result_in_b == NULL: xlbhip_run's fixed placement; else as xlbhip_run_any)
+  if (int rc = run_steps(s, a, b, bcm, miss, omega, n, result_in_b == nullptr, result_in_b)) return rc;
   XLB_HIP(hipEventRecord(c->ev_b, c->stream));
   XLB_HIP(hipEventSynchronize(c->ev_b));
   XLB_HIP(hipEventElapsedTime(ms, c->ev_a, c->ev_b));

@@ -109,8 +109,8 @@ class IncompressibleNavierStokesStepper(Stepper):
         """``n_steps`` x (step, swap) in native code; returns (f_current, f_other)."""
         if f_0.halo > 0 and self._ctx.get_option("external_halo"):
             return self._run_host_staged(f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep)
-        self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
-        return (f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)
+        in_b = self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
+        return (f_1, f_0) if in_b else (f_0, f_1)
 
     def run_timed(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """As :meth:`run`; also returns the device time in ms measured with HIP events."""
@@ -122,8 +122,8 @@ class IncompressibleNavierStokesStepper(Stepper):
             out = self._run_host_staged(f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep)
             self._ctx.sync()
             return out, (time.perf_counter() - t0) * 1e3
-        ms = self._native_stepper().run_timed(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
-        return ((f_0, f_1) if n_steps % 2 == 0 else (f_1, f_0)), ms
+        in_b, ms = self._native_stepper().run_timed(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
+        return ((f_1, f_0) if in_b else (f_0, f_1)), ms
 
     def _run_host_staged(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep):
         """The native run loop with the ghost planes moved by the host (``init_process_group(transport="host")``):
