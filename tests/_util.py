@@ -11,7 +11,6 @@ from xlb_amd import ComputeBackend, PrecisionPolicy
 from xlb_amd.grid import grid_factory
 from xlb_amd.operator.boundary_condition import EquilibriumBC, FullwayBounceBackBC, HalfwayBounceBackBC
 from xlb_amd.operator.macroscopic import Macroscopic
-from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 VS = {"D2Q9": xlb_amd.velocity_set.D2Q9, "D3Q19": xlb_amd.velocity_set.D3Q19, "D3Q27": xlb_amd.velocity_set.D3Q27}

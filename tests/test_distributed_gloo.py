@@ -6,7 +6,6 @@ import socket
 import subprocess
 import sys
 
-import numpy as np
 import pytest
 
 from oracle import xlb_numpy as orc

@@ -7,7 +7,7 @@ import pytest
 
 import xlb_amd
 from oracle import xlb_numpy as orc
-from xlb_amd import ComputeBackend, Precision, PrecisionPolicy
+from xlb_amd import ComputeBackend, Precision
 from xlb_amd import _lib
 from xlb_amd.grid import grid_factory
 from xlb_amd.helper import create_nse_fields

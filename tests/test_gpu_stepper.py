@@ -7,7 +7,6 @@ import numpy as np
 import pytest
 
 from oracle import xlb_numpy as orc
-from xlb_amd import ComputeBackend, PrecisionPolicy
 from xlb_amd.default_config import get_context
 from xlb_amd.grid import grid_factory
 from xlb_amd.operator.boundary_condition import FullwayBounceBackBC, HalfwayBounceBackBC, EquilibriumBC, DoNothingBC

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from .. import _lib
-from ..default_config import DefaultConfig, get_context
+from ..default_config import get_context
 from ..grid.hip_grid import slab_bounds
 
 _state = {"dist": None, "rank": 0, "world": 1}
