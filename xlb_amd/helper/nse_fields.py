@@ -8,16 +8,18 @@ from ..grid import grid_factory
 from ..precision_policy import Precision
 
 
+def _or_default(value, name):
+    return getattr(DefaultConfig, name) if value is None else value
+
+
 def create_nse_fields(grid_shape=None, grid=None, velocity_set=None, compute_backend=None, precision_policy=None):
-    velocity_set = velocity_set or DefaultConfig.velocity_set
-    compute_backend = compute_backend or DefaultConfig.default_backend
-    precision_policy = precision_policy or DefaultConfig.default_precision_policy
-    if grid is None:
-        if grid_shape is None:
-            raise ValueError("grid_shape must be provided when grid is None")
-        grid = grid_factory(grid_shape, compute_backend=compute_backend, velocity_set=velocity_set)
-    f_0 = grid.create_field(cardinality=velocity_set.q, dtype=precision_policy.store_precision)
-    f_1 = grid.create_field(cardinality=velocity_set.q, dtype=precision_policy.store_precision)
-    bc_mask = grid.create_field(cardinality=1, dtype=Precision.UINT8)
-    missing_mask = grid.create_missing_mask(velocity_set.q)
-    return grid, f_0, f_1, missing_mask, bc_mask
+    """-> (grid, f_0, f_1, missing_mask, bc_mask); the grid is built from ``grid_shape`` unless one is passed in."""
+    lattice = _or_default(velocity_set, "velocity_set")
+    backend = _or_default(compute_backend, "default_backend")
+    store = _or_default(precision_policy, "default_precision_policy").store_precision
+    if grid is None and grid_shape is None:
+        raise ValueError("grid_shape must be provided when grid is None")
+    grid = grid or grid_factory(grid_shape, compute_backend=backend, velocity_set=lattice)
+    populations = [grid.create_field(lattice.q, store) for _ in range(2)]  # f_0, f_1 (the A/B pair)
+    masks = {"missing": grid.create_missing_mask(lattice.q), "bc": grid.create_field(1, Precision.UINT8)}
+    return (grid, *populations, masks["missing"], masks["bc"])
