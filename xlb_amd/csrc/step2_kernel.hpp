@@ -1,13 +1,13 @@
 // Two LBM steps per pass over memory ("temporal fusion"): f(t) -> f(t+2) with the intermediate
 // f(t+1) living only in LDS.
 //
-// A block owns a (TY x TZ) tile of the (y, z) plane and marches along x.  For every x it
-//   phase A: computes f(t+1) on plane x+1 for the tile grown by one cell in y and z
-//            ((TY+2) x (TZ+2) cells, periodic images included) by pulling from f(t) in global
-//            memory — exactly the single-step kernel's work — and writes the q populations into one
-//            of three LDS plane slots;
+// A block owns a (TY x TZ) tile of the (y, z) plane and marches along (a segment of) x.  For every x it
 //   phase B: computes f(t+2) on plane x for the tile proper by pulling from the three LDS slots
-//            (planes x-1, x, x+1) and stores it.
+//            (planes x-1, x, x+1) and stores it;
+//   phase A: computes f(t+1) on plane x+2 for the tile grown by one cell in y and z
+//            ((TY+2) x (TZ+2) cells, periodic images included) from pulls of f(t) in global memory that were
+//            issued one plane earlier — exactly the single-step kernel's work — writes the q populations into
+//            the LDS slot plane x-1 just vacated, and issues the pulls of plane x+3.
 // HBM traffic per two steps: ~(1 + halo overlap) reads + 1 write of every population instead of
 // 2 + 2.  Arithmetic is the same per-cell code (cell.hpp) in the same order, so the result is
 // bit-identical to two single steps (tests/test_gpu_stepper.py::test_two_step_fusion_*).
