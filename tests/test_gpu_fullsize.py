@@ -65,3 +65,34 @@ def test_cavity_512_symmetry(walls_cls):
     assert np.abs(u[0] - u[0][:, ::-1, :]).max() <= sym and np.abs(u[2] - u[2][:, ::-1, :]).max() <= sym
     assert np.abs(u[1] + u[1][:, ::-1, :]).max() <= sym
     assert float(np.abs(u[0]).max()) > 1e-3  # the lid actually drives the flow
+
+
+@pytest.mark.parametrize("walls_cls", [HalfwayBounceBackBC, FullwayBounceBackBC])
+def test_cavity_512_two_step_kernel_equals_single_step_kernel(walls_cls):
+    """BASELINE configs[2] at full size: 120 steps through the two-steps-per-pass kernel (hand-counted vmcnt, inline-asm
+    fix-up loads, 4096 work items) and through the single-step kernel give the SAME BITS in all 19 x 512^3 populations.
+    (The small-size tests compare both kernels with the oracle; this one exercises the full-size schedule.)"""
+    from xlb_amd.default_config import get_context
+
+    n, steps = 512, 120
+    grid, bcs, lat, obcs = hip_cavity_3d((n, n, n), walls_cls)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    ctx = get_context()
+    assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    digests = []
+    try:
+        for fuse2 in (1, 0):
+            ctx.set_option("fuse2", fuse2)
+            # the driver's start (f = w everywhere), identical for both runs
+            init = orc.initialize_eq((1, 1, 1), lat).reshape(19)
+            f_0.assign(np.broadcast_to(init.reshape(19, 1, 1, 1), (19, n, n, n)).astype(np.float32))
+            a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, steps)
+            out = a.numpy()
+            assert np.isfinite(out).all()
+            digests.append(out)
+            f_0, f_1 = (a, b) if a is f_0 else (b, a)
+    finally:
+        ctx.set_option("fuse2", 1)
+    assert np.array_equal(digests[0], digests[1])
+    assert float(np.abs(digests[0] - digests[0][:, :1, :1, :1]).max()) > 1e-4  # the lid drove a flow: not a trivial comparison
