@@ -96,3 +96,21 @@ def test_cavity_512_two_step_kernel_equals_single_step_kernel(walls_cls):
         ctx.set_option("fuse2", 1)
     assert np.array_equal(digests[0], digests[1])
     assert float(np.abs(digests[0] - digests[0][:, :1, :1, :1]).max()) > 1e-4  # the lid drove a flow: not a trivial comparison
+
+
+def test_cavity_512_slab_layout_equals_plain_layout():
+    """The multi-rank field layout (two ghost planes, depth-2 ring exchange onto the rank itself, interior launch
+    overlapped with the exchange + two edge launches) against the plain layout at BASELINE configs[2] size: same bits
+    after 41 steps (20 fused pairs + one single step with the depth-1 exchange)."""
+    n, steps = 512, 41
+    outs = []
+    for cfg in (None, {"halo": 2}):
+        grid, bcs, lat, obcs = hip_cavity_3d((n, n, n), HalfwayBounceBackBC, backend_config=cfg)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, steps)
+        outs.append(a.numpy())
+        for fld in (f_0, f_1, bc_mask, missing_mask):
+            fld.free()
+    assert np.array_equal(outs[0], outs[1])
