@@ -32,12 +32,14 @@ ap.add_argument("--nz", type=int, default=96)
 ap.add_argument("--steps", type=int, default=2000)
 ap.add_argument("--re", type=float, default=100.0)
 ap.add_argument("--u-max", type=float, default=0.04)
+ap.add_argument("--fuse2", type=int, default=1, help="0: single-step kernel only; 1: two steps per pass where the library finds it eligible")
 args = ap.parse_args()
 
 policy = PrecisionPolicy.FP32FP32
 lattice = xlb.velocity_set.D3Q19(precision_policy=policy, compute_backend=ComputeBackend.HIP)
 xlb.init(velocity_set=lattice, default_backend=ComputeBackend.HIP, default_precision_policy=policy)
 
+xlb.default_config.get_context().set_option("fuse2", args.fuse2)
 shape = (args.nx, args.ny, args.nz)
 grid = grid_factory(shape)
 box = grid.bounding_box_indices()

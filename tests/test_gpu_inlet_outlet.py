@@ -298,3 +298,70 @@ def test_flow_past_sphere_vs_golden():
     assert np.array_equal(mag.numpy(), g["vorticity_magnitude"]) and np.array_equal(q.numpy(), g["q"])
     force = MomentumTransfer(b_s)(f_0, f_1, bc_mask, missing_mask)
     assert np.allclose(force, g["force"], rtol=1e-5, atol=1e-5 * np.abs(g["force"]).max())
+
+
+@pytest.mark.parametrize("steps", [2, 5, 8])
+@pytest.mark.parametrize("outlet", ["outflow", "pressure"])
+def test_two_step_kernel_with_inlet_outlet_planes(outlet, steps):
+    """Steppers whose Zou-He / Regularized / outflow cells all sit in the planes x = 0 and x = nx-1 still use the two-step
+    kernel for the planes 2 .. nx-3; the four end planes go through the single-step kernel twice (api.hip:
+    step_twice_edge_ext).  Same bits as the oracle — i.e. as the single-step path — for every step-count parity."""
+    from xlb_amd.default_config import get_context
+
+    shape = (24, 16, 64)
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    walls = [sum((box[f][i] for f in ("bottom", "top", "front", "back")), []) for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    x, y, z = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+    sphere = [s.tolist() for s in np.where((x - 8) ** 2 + (y - 8) ** 2 + (z - 30) ** 2 < 3.3**2)]
+    prof = parabolic_inlet(shape)
+    b_w = HalfwayBounceBackBC(indices=walls)
+    b_in = RegularizedBC("velocity", profile=lambda: prof, indices=box_ne["left"])
+    if outlet == "outflow":
+        b_out = ExtrapolationOutflowBC(indices=box_ne["right"])
+        o_out = orc.BC(orc.KIND_EXTRAPOLATION_OUTFLOW, b_out.id, box_ne["right"])
+    else:
+        b_out = ZouHeBC("pressure", prescribed_value=1.0, indices=box_ne["right"])
+        o_out = orc.BC(orc.KIND_ZOUHE_PRESSURE, b_out.id, box_ne["right"], prescribed=1.0)
+    b_s = HalfwayBounceBackBC(indices=sphere)
+    obcs = [orc.BC(orc.KIND_HALFWAY_BB, b_w.id, walls), orc.BC(orc.KIND_REGULARIZED_VELOCITY, b_in.id, box_ne["left"], prescribed=prof), o_out,
+            orc.BC(orc.KIND_HALFWAY_BB, b_s.id, sphere)]
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_w, b_in, b_out, b_s])
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        f_np = orc.perturbed_init(shape, lat, seed=51)
+        f_0.assign(f_np)
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, steps)
+        with np.errstate(all="ignore"):
+            exp = orc.run(f_np, o_bm, o_mm, obcs, 1.5, lat, steps)
+        out = a.numpy()
+        assert np.array_equal(out, exp), f"max ulp {max_ulp_diff(out, exp)}, max abs {np.abs(out - exp).max()}"
+    finally:
+        ctx.set_option("fuse2", 1)
+
+
+def test_two_step_kernel_refuses_interior_inlets():
+    """an extended BC away from the end planes keeps the stepper on the single-step kernel"""
+    from xlb_amd.default_config import get_context
+
+    shape = (24, 16, 64)
+    vs, pp = init_hip("D3Q19")
+    grid = grid_factory(shape)
+    plane3 = [[3] * 4, [4, 5, 6, 7], [10, 11, 12, 13]]
+    b = ZouHeBC("velocity", prescribed_value=(0.01, 0.0, 0.0), indices=plane3)
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b])
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert not stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    finally:
+        ctx.set_option("fuse2", 1)

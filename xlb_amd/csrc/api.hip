@@ -675,6 +675,10 @@ struct xlbhip_stepper {
   bool needs_missing = false;
   bool extended_bcs = false;
   bool has_outflow = false;  // ExtrapolationOutflowBC present: k_outflow_aux runs after every step
+  // two-step kernel with extended BCs on the x end planes only (inlet / outlet): the end planes go through the
+  // single-step kernel twice via this third population field
+  xlbhip_field* scratch = nullptr;
+  bool edge_ext_ok = false;
   uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
   int order_ty = 0, order_tz = 0;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
@@ -763,6 +767,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.store_dtype = s->sdt;
   p.vec = (int)opt(c, "vec", 0);
   p.has_bc = p.bc != nullptr ? (s->extended_bcs ? 2 : 1) : 0;
+  p.edge_ext = s->edge_ext_ok ? 1 : 0;
   p.flags = (opt(c, "nt_store", 1) ? 1 : 0) | (int)(opt(c, "nt_load", 0) << 1);
   p.block_threads = (int)opt(c, "block_threads", 256);
   p.block_tz = (int)opt(c, "block_tz", 0);
@@ -799,6 +804,62 @@ static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
   return best;
 }
 
+// assemble_auxiliary_data of the ExtrapolationOutflowBC cells after a step src -> dst (nse_stepper.py:270-272)
+static int outflow_aux(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
+  if (!s->has_outflow) return 0;
+  xlbhip_ctx* c = s->ctx;
+  const size_t n = dst->cells();
+  return by_lattice(s->lattice, [&](auto L) {
+    using LL = decltype(L);
+    if (s->cdt == XLBHIP_F32)
+      hipLaunchKernelGGL((k_outflow_aux<LL, float>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
+                         s->tab_kind, static_cast<const float*>(s->tab_values), s->prof_keys, static_cast<const float*>(s->prof_vals), s->n_prof);
+    else
+      hipLaunchKernelGGL((k_outflow_aux<LL, double>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
+                         s->tab_kind, static_cast<const double*>(s->tab_values), s->prof_keys, static_cast<const double*>(s->prof_vals), s->n_prof);
+    XLB_HIP(hipGetLastError());
+    return 0;
+  });
+}
+
+static int launch_any(const xlbhip_stepper* s, const StepLaunch& p);
+
+// Pair of steps for a stepper whose Zou-He / Regularized / outflow cells all sit in the planes x = 0 and x = nx - 1
+// (inlet / outlet faces): the two-step kernel updates the planes 2 .. nx-3, whose two-step cone never evaluates such a
+// cell (its f(t+1) on the planes 1 and nx-2 only PULLS from the end planes), and the four end planes go through the
+// single-step kernel twice with a third population field holding their f(t+1).
+static int step_twice_edge_ext(xlbhip_stepper* s, StepLaunch p, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm,
+                               const xlbhip_field* miss, double omega) {
+  xlbhip_ctx* c = s->ctx;
+  if (!s->scratch || s->scratch->nx != src->nx || s->scratch->ny != src->ny || s->scratch->nz != src->nz || s->scratch->dtype != src->dtype) {
+    if (s->scratch) xlbhip_field_destroy(s->scratch);
+    s->scratch = nullptr;
+    if (int rc = xlbhip_field_create(c, src->card, src->nx, src->ny, src->nz, src->dtype, src->halo, 0.0, &s->scratch)) return rc;
+    XLB_REQUIRE(s->scratch->plane_stride == src->plane_stride, "scratch field layout differs from the population fields");
+  }
+  const int nx = src->nx;
+  p.x_begin = 2;
+  p.x_count = nx - 4;
+  p.x_segments = fuse2_segments(s, p);
+  if (int rc = launch_step2_d3q19_bgk(p)) return rc;
+  // end planes, step 1: f(t+1) on the planes nx-3 .. nx-1 and 0 .. 2 -> scratch
+  StepLaunch q = make_launch(s, src, s->scratch, bcm, miss, omega);
+  q.x_begin = nx - 3;
+  q.x_count = 3;
+  if (int rc = launch_any(s, q)) return rc;
+  q.x_begin = 0;
+  if (int rc = launch_any(s, q)) return rc;
+  if (int rc = outflow_aux(s, src, s->scratch, bcm, miss)) return rc;
+  // step 2: f(t+2) on the planes nx-2, nx-1, 0, 1 -> dst
+  StepLaunch r = make_launch(s, s->scratch, dst, bcm, miss, omega);
+  r.x_begin = nx - 2;
+  r.x_count = 2;
+  if (int rc = launch_any(s, r)) return rc;
+  r.x_begin = 0;
+  if (int rc = launch_any(s, r)) return rc;
+  return outflow_aux(s, s->scratch, dst, bcm, miss);
+}
+
 // two steps in one pass (a -> scratch-free: src -> dst holds f(t+2)); caller checked eligibility
 static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                       double omega) {
@@ -811,6 +872,7 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   p.x_segments = fuse2_segments(s, p);
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
+  if (s->extended_bcs) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
   if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2_d3q19_bgk(p);
   // slab protocol for a PAIR of steps: the two ghost planes per side of src are refilled on the comm stream
   // (comm.cpp, depth 2) while the planes whose two-step cone stays inside the slab are updated; the two edge
@@ -840,6 +902,22 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
 static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
   const int64_t mode = opt(s->ctx, "fuse2", 1);
   if (mode == 0 || s->forced) return false;
+  s->edge_ext_ok = false;
+  if (s->extended_bcs) {
+    // Zou-He / Regularized / outflow cells: fine when they all sit in the two x end planes (scan of bc_mask, 1 B / cell)
+    if (!bcm || src->halo != 0 || src->nx < 16 || s->lattice != XLBHIP_D3Q19) return false;
+    xlbhip_ctx* c = s->ctx;
+    int* dflag = nullptr;
+    int flag = 1;
+    if (hipMalloc(&dflag, sizeof(int)) != hipSuccess) return false;
+    (void)hipMemsetAsync(dflag, 0, sizeof(int), c->stream);
+    hipLaunchKernelGGL(k_ext_interior_scan, blocks_for(bcm->cells()), 256, 0, c->stream, view(bcm), s->tab_kind, dims(bcm), dflag);
+    if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+      flag = 1;
+    (void)hipFree(dflag);
+    if (flag != 0) return false;
+    s->edge_ext_ok = true;
+  }
   StepLaunch p = make_launch(s, src, dst, bcm, miss, 1.0);
   if (!step2_eligible(p, s->lattice, s->collision)) return false;
   if (mode == 1) {
@@ -948,20 +1026,7 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
 static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                      double omega) {
   if (int rc = step_kernels(s, src, dst, bcm, miss, omega)) return rc;
-  if (!s->has_outflow) return 0;
-  xlbhip_ctx* c = s->ctx;
-  const size_t n = dst->cells();
-  return by_lattice(s->lattice, [&](auto L) {
-    using LL = decltype(L);
-    if (s->cdt == XLBHIP_F32)
-      hipLaunchKernelGGL((k_outflow_aux<LL, float>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
-                         s->tab_kind, static_cast<const float*>(s->tab_values), s->prof_keys, static_cast<const float*>(s->prof_vals), s->n_prof);
-    else
-      hipLaunchKernelGGL((k_outflow_aux<LL, double>), blocks_for(n), 256, 0, c->stream, view(src), view(dst), view(bcm), view(miss), dims(dst),
-                         s->tab_kind, static_cast<const double*>(s->tab_values), s->prof_keys, static_cast<const double*>(s->prof_vals), s->n_prof);
-    XLB_HIP(hipGetLastError());
-    return 0;
-  });
+  return outflow_aux(s, src, dst, bcm, miss);
 }
 
 }  // namespace xlb
@@ -1093,6 +1158,7 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   (void)hipFree(s->tab_values);
   if (s->prof_keys) (void)hipFree(s->prof_keys);
   if (s->prof_vals) (void)hipFree(s->prof_vals);
+  if (s->scratch) xlbhip_field_destroy(s->scratch);
   if (s->meta) (void)hipFree(s->meta);
   if (s->tile_order) (void)hipFree(s->tile_order);
   delete s;

@@ -271,6 +271,15 @@ __global__ void k_velocity_gradient(FieldView u, FieldView bc, FieldView out_a, 
   }
 }
 
+// any Zou-He / Regularized / outflow cell strictly inside the x range?  (two-step kernel with inlet / outlet planes)
+__global__ void k_ext_interior_scan(FieldView bc, const uint8_t* kind_tab, Dims d, int* flag) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  if (x < 1 || x > d.nx - 2) return;
+  const unsigned id = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+  if (id != 0u && kind_tab[id] >= XLBHIP_BC_ZOUHE_VELOCITY) *flag = 1;
+}
+
 // ---- MomentumTransfer (force/momentum_transfer.py:167-205, JAX): force on the solid behind a no-slip BC ----------
 // f0 holds post-collision populations.  At every cell of the BC that is not itself solid (rest direction not
 // missing), for every missing direction l:  phi_l = f0[opp l] + f_post_stream[l],  f_post_stream[l] = the BC's

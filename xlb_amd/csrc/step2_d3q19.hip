@@ -9,7 +9,8 @@ bool step2_eligible(const StepLaunch& p, int lattice, int collision) {
   for (int i = 0; i < p.n_bc && i < 8; ++i)
     if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING) return false;
   return lattice == XLBHIP_D3Q19 && collision == XLBHIP_BGK && p.compute_dtype == XLBHIP_F32 && p.store_dtype == XLBHIP_F32 &&
-         (p.halo == 0 || p.halo == 2) && p.has_bc <= 1 && p.n_bc <= MAX_FAST_BCS && p.ny % 8 == 0 && p.nz % 64 == 0 && p.nx >= 4;
+         (p.halo == 0 || p.halo == 2) && (p.has_bc <= 1 || (p.edge_ext && p.halo == 0 && p.nx >= 16)) && p.n_bc <= MAX_FAST_BCS &&
+         p.ny % 8 == 0 && p.nz % 64 == 0 && p.nx >= 4;
 }
 
 template <int HASBC, int TY, int TZ, bool SLAB>

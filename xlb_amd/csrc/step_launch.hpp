@@ -31,6 +31,7 @@ struct StepLaunch {
   int compute_dtype, store_dtype;
   int vec;     // requested cells per thread (1, 2, 4); must divide nz
   int has_bc;  // 0: no BCs; 1: basic kinds; 2: + Zou-He / Regularized
+  int edge_ext;  // has_bc == 2 but every extended-kind cell sits in plane 0 or nx - 1 (two-step kernel: interior planes only)
   int flags;   // bit 0: non-temporal stores
   int block_threads;  // 0 = default (256)
   int block_tz;       // threads along z per block, 0 = as many as fit
