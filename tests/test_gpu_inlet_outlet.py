@@ -365,3 +365,38 @@ def test_two_step_kernel_refuses_interior_inlets():
         assert not stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
     finally:
         ctx.set_option("fuse2", 1)
+
+
+@pytest.mark.parametrize("steps", [2, 7])
+def test_two_step_kernel_with_do_nothing_outlet(steps):
+    """DoNothingBC on the outlet plane: same route as the Zou-He family (end planes through the single-step kernel)."""
+    from xlb_amd.default_config import get_context
+    from xlb_amd.operator.boundary_condition import DoNothingBC, EquilibriumBC
+
+    shape = (20, 16, 64)
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    box_ne = grid.bounding_box_indices(remove_edges=True)
+    walls = [sum((box[f][i] for f in ("bottom", "top", "front", "back")), []) for i in range(3)]
+    walls = np.unique(np.array(walls), axis=-1).tolist()
+    b_in = EquilibriumBC(rho=1.0, u=(0.03, 0.0, 0.0), indices=box_ne["left"])
+    b_out = DoNothingBC(indices=box_ne["right"])
+    b_w = HalfwayBounceBackBC(indices=walls)
+    obcs = [orc.BC(orc.KIND_EQUILIBRIUM, b_in.id, box_ne["left"], rho=1.0, u=(0.03, 0.0, 0.0)), orc.BC(orc.KIND_DO_NOTHING, b_out.id, box_ne["right"]),
+            orc.BC(orc.KIND_HALFWAY_BB, b_w.id, walls)]
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_in, b_out, b_w])
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        f_np = orc.perturbed_init(shape, lat, seed=53)
+        f_0.assign(f_np)
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, steps)
+        exp = orc.run(f_np, o_bm, o_mm, obcs, 1.3, lat, steps)
+        assert np.array_equal(a.numpy(), exp)
+    finally:
+        ctx.set_option("fuse2", 1)

@@ -679,6 +679,7 @@ struct xlbhip_stepper {
   // single-step kernel twice via this third population field
   xlbhip_field* scratch = nullptr;
   bool edge_ext_ok = false;
+  bool has_edge_kinds = false;  // kinds the two-step kernel does not evaluate itself: Zou-He family, outflow, do-nothing
   uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
   int order_ty = 0, order_tz = 0;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
@@ -872,7 +873,7 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   p.x_segments = fuse2_segments(s, p);
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
-  if (s->extended_bcs) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
+  if (s->edge_ext_ok) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
   if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2_d3q19_bgk(p);
   // slab protocol for a PAIR of steps: the two ghost planes per side of src are refilled on the comm stream
   // (comm.cpp, depth 2) while the planes whose two-step cone stays inside the slab are updated; the two edge
@@ -903,8 +904,8 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   const int64_t mode = opt(s->ctx, "fuse2", 1);
   if (mode == 0 || s->forced) return false;
   s->edge_ext_ok = false;
-  if (s->extended_bcs) {
-    // Zou-He / Regularized / outflow cells: fine when they all sit in the two x end planes (scan of bc_mask, 1 B / cell)
+  if (s->has_edge_kinds) {
+    // Zou-He / Regularized / outflow / do-nothing cells: fine when they all sit in the two x end planes (scan of bc_mask, 1 B / cell)
     if (!bcm || src->halo != 0 || src->nx < 16 || s->lattice != XLBHIP_D3Q19) return false;
     xlbhip_ctx* c = s->ctx;
     int* dflag = nullptr;
@@ -1045,12 +1046,13 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   std::vector<uint8_t> kind(256, 0);
   const int q = lattice_q(lattice);
   std::vector<double> vals(256 * 27, 0.0);
-  bool needs_missing = false, extended = false, has_outflow = false;
+  bool needs_missing = false, extended = false, has_outflow = false, has_edge_kinds = false;
   for (int i = 0; i < n_bc; ++i) {
     const xlbhip_bc_desc& b = bcs[i];
     XLB_REQUIRE(b.id >= 1 && b.id <= 255, "bc id %d out of range 1..255", b.id);
     XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_EXTRAPOLATION_OUTFLOW, "unknown bc kind %d", b.kind);
     if (b.kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) has_outflow = true;
+    if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY || b.kind == XLBHIP_BC_DO_NOTHING) has_edge_kinds = true;
     XLB_REQUIRE(kind[b.id] == 0, "bc id %d used twice", b.id);
     if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY) extended = needs_missing = true;
     kind[b.id] = (uint8_t)b.kind;
@@ -1078,6 +1080,7 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   s->needs_missing = needs_missing;
   s->extended_bcs = extended;
   s->has_outflow = has_outflow;
+  s->has_edge_kinds = has_edge_kinds;
   s->ids_packed = ids_packed;
   s->kinds_packed = kinds_packed;
   s->moving_mask = moving_mask;

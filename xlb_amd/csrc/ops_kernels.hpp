@@ -271,13 +271,13 @@ __global__ void k_velocity_gradient(FieldView u, FieldView bc, FieldView out_a, 
   }
 }
 
-// any Zou-He / Regularized / outflow cell strictly inside the x range?  (two-step kernel with inlet / outlet planes)
+// any Zou-He / Regularized / outflow / do-nothing cell strictly inside the x range?  (two-step kernel with inlet / outlet planes)
 __global__ void k_ext_interior_scan(FieldView bc, const uint8_t* kind_tab, Dims d, int* flag) {
   int x, y, z;
   if (!cell_of_thread(d, x, y, z)) return;
   if (x < 1 || x > d.nx - 2) return;
   const unsigned id = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
-  if (id != 0u && kind_tab[id] >= XLBHIP_BC_ZOUHE_VELOCITY) *flag = 1;
+  if (id != 0u && (kind_tab[id] >= XLBHIP_BC_ZOUHE_VELOCITY || kind_tab[id] == XLBHIP_BC_DO_NOTHING)) *flag = 1;
 }
 
 // ---- MomentumTransfer (force/momentum_transfer.py:167-205, JAX): force on the solid behind a no-slip BC ----------

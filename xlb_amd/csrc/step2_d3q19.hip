@@ -5,9 +5,10 @@
 namespace xlb {
 
 bool step2_eligible(const StepLaunch& p, int lattice, int collision) {
-  // do-nothing BCs would need a second redirected-load form (own cell, same population): not built, single-step kernel instead
+  // do-nothing BCs would need a second redirected-load form (own cell, same population): not built; like the Zou-He
+  // family they are fine on the x end planes, which the two-step kernel leaves to the single-step kernel (edge_ext)
   for (int i = 0; i < p.n_bc && i < 8; ++i)
-    if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING) return false;
+    if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING && !p.edge_ext) return false;
   return lattice == XLBHIP_D3Q19 && collision == XLBHIP_BGK && p.compute_dtype == XLBHIP_F32 && p.store_dtype == XLBHIP_F32 &&
          (p.halo == 0 || p.halo == 2) && (p.has_bc <= 1 || (p.edge_ext && p.halo == 0 && p.nx >= 16)) && p.n_bc <= MAX_FAST_BCS &&
          p.ny % 8 == 0 && p.nz % 64 == 0 && p.nx >= 4;
