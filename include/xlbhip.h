@@ -149,6 +149,10 @@ int xlbhip_momentum_transfer(xlbhip_ctx* ctx, int lattice, int compute_dtype, co
  * the outputs is left untouched).  Arithmetic in u's dtype (fp32 / fp64). */
 int xlbhip_vorticity(xlbhip_ctx* ctx, const xlbhip_field* u, const xlbhip_field* bc_mask, xlbhip_field* vorticity,
                      xlbhip_field* vorticity_magnitude);
+/* GridToPoint()(grid, points, point_values): postprocess/grid_to_point.py:28-104 — trilinear interpolation of component 0 of a
+ * 3-D field at n points (host float[n][3] in, host values[n] in the field's dtype out; synchronous).  Unlike the reference,
+ * points whose surrounding cube leaves the field are an error instead of an out-of-bounds read. */
+int xlbhip_grid_to_point(xlbhip_ctx* ctx, const xlbhip_field* grid, int64_t n, const float* points, void* point_values);
 /* QCriterion()(u, bc_mask, norm_mu, q): postprocess/q_criterion.py:36-139; Q = (|Omega|^2 - |S|^2) / 2, same cells */
 int xlbhip_q_criterion(xlbhip_ctx* ctx, const xlbhip_field* u, const xlbhip_field* bc_mask, xlbhip_field* norm_mu, xlbhip_field* q);
 /* BGK()/KBC()(f, feq, fout, omega): bgk.py:27-32,:78-91; kbc.py:40-79 */

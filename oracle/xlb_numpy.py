@@ -725,3 +725,23 @@ def sphere_channel(shape=(28, 14, 14), u_max=0.04, inlet_kind=KIND_REGULARIZED_V
            BC(KIND_HALFWAY_BB, 4, sphere)]
     return lat, bcs, prof
 
+
+def grid_to_point(grid, points):
+    """GridToPoint, postprocess/grid_to_point.py:28-94: trilinear interpolation of grid[0] at points (n, 3) float32."""
+    T = grid.dtype.type
+    p = np.asarray(points, dtype=np.float32)
+    lo = p.astype(np.int32)
+    d = p - lo.astype(np.float32)
+    dx, dy, dz = d[:, 0], d[:, 1], d[:, 2]
+    one = np.float32(1.0)
+    g = lambda a, b, c: grid[0, lo[:, 0] + a, lo[:, 1] + b, lo[:, 2] + c]  # noqa: E731
+    v = ((one - dx) * (one - dy) * (one - dz)).astype(T) * g(0, 0, 0)
+    v = v + ((one - dx) * (one - dy) * dz).astype(T) * g(0, 0, 1)
+    v = v + ((one - dx) * dy * (one - dz)).astype(T) * g(0, 1, 0)
+    v = v + ((one - dx) * dy * dz).astype(T) * g(0, 1, 1)
+    v = v + (dx * (one - dy) * (one - dz)).astype(T) * g(1, 0, 0)
+    v = v + (dx * (one - dy) * dz).astype(T) * g(1, 0, 1)
+    v = v + (dx * dy * (one - dz)).astype(T) * g(1, 1, 0)
+    v = v + (dx * dy * dz).astype(T) * g(1, 1, 1)
+    return v
+

@@ -159,3 +159,30 @@ def test_momentum_transfer_on_a_sphere(policy):
     fw = MomentumTransfer(b_w)(f_0, f_1, bc_mask, missing_mask)
     exp_fw = orc.momentum_transfer(f_0.numpy(), obcs[0], o_bm, o_mm, lat, policy)
     assert np.allclose(fw, exp_fw, rtol=10 * tol, atol=10 * tol * np.abs(exp_fw).max()), (fw, exp_fw)
+
+
+@pytest.mark.parametrize("prec", [Precision.FP32, Precision.FP64])
+def test_grid_to_point_vs_oracle(prec):
+    from xlb_amd.grid import grid_factory
+    from xlb_amd.operator.postprocess import GridToPoint
+
+    vs, pp = init_hip("D3Q19")
+    shape = (9, 7, 11)
+    grid = grid_factory(shape)
+    T = prec.np_dtype
+    rng = np.random.default_rng(4)
+    g_np = rng.standard_normal((1,) + shape).astype(T)
+    fld = grid.create_field(1, dtype=prec).assign(g_np)
+    pts = (rng.random((200, 3)) * (np.array(shape) - 1.001)).astype(np.float32)
+    pts[:3] = [[0, 0, 0], [2.0, 3.0, 4.0], [7.5, 5.25, 9.75]]  # grid nodes reproduce the node value exactly
+    out = GridToPoint()(fld, pts, np.empty(200, T))
+    assert np.array_equal(out, orc.grid_to_point(g_np, pts))
+    assert out[0] == g_np[0, 0, 0, 0] and out[1] == g_np[0, 2, 3, 4]
+    # a linear field is reproduced by trilinear interpolation
+    x, y, z = np.meshgrid(*[np.arange(n, dtype=T) for n in shape], indexing="ij")
+    lin = (0.5 * x - 0.25 * y + 2.0 * z + 1.0)[None]
+    fld.assign(lin)
+    out = GridToPoint()(fld, pts, np.empty(200, T))
+    assert np.allclose(out, 0.5 * pts[:, 0] - 0.25 * pts[:, 1] + 2.0 * pts[:, 2] + 1.0, atol=1e-4)
+    with pytest.raises(Exception, match="outside the field"):
+        GridToPoint()(fld, np.array([[8.5, 1.0, 1.0]], np.float32), np.empty(1, T))

@@ -494,6 +494,44 @@ int xlbhip_momentum_transfer(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_b
   return rc;
 }
 
+int xlbhip_grid_to_point(xlbhip_ctx* c, const xlbhip_field* grid, int64_t n, const float* points, void* values) {
+  XLB_REQUIRE(c && grid && (n == 0 || (points && values)), "grid_to_point: null argument");
+  XLB_REQUIRE((grid->dtype == XLBHIP_F32 || grid->dtype == XLBHIP_F64) && grid->halo == 0, "grid_to_point: fp32 / fp64 field without ghost planes");
+  if (n == 0) return 0;
+  // every point needs its surrounding cube inside the field (the reference does not check; an out-of-range point reads
+  // out of bounds there)
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float p = points[3 * i + a];
+      const int ext = a == 0 ? grid->nx : (a == 1 ? grid->ny : grid->nz);
+      XLB_REQUIRE(p >= 0.0f && (int)p + 1 <= ext - 1, "grid_to_point: point %lld (%g along axis %d) needs cells outside the field", (long long)i,
+                  (double)p, a);
+    }
+  const size_t es = dtype_size(grid->dtype);
+  float* dp = nullptr;
+  void* dv = nullptr;
+  XLB_HIP(hipMalloc(&dp, (size_t)n * 3 * sizeof(float)));
+  hipError_t e = hipMalloc(&dv, (size_t)n * es);
+  if (e != hipSuccess) {
+    (void)hipFree(dp);
+    XLB_FAIL("grid_to_point: %s", hipGetErrorString(e));
+  }
+  e = hipMemcpyAsync(dp, points, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    if (grid->dtype == XLBHIP_F32)
+      hipLaunchKernelGGL((k_grid_to_point<float>), blocks_for((size_t)n), 256, 0, c->stream, view(grid), dims(grid), dp, static_cast<float*>(dv), n);
+    else
+      hipLaunchKernelGGL((k_grid_to_point<double>), blocks_for((size_t)n), 256, 0, c->stream, view(grid), dims(grid), dp, static_cast<double*>(dv), n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(values, dv, (size_t)n * es, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dp);
+  (void)hipFree(dv);
+  XLB_REQUIRE(e == hipSuccess, "grid_to_point: %s", hipGetErrorString(e));
+  return 0;
+}
+
 int xlbhip_vorticity(xlbhip_ctx* c, const xlbhip_field* u, const xlbhip_field* bcm, xlbhip_field* vorticity, xlbhip_field* magnitude) {
   return velocity_gradient_launch<0>(c, u, bcm, vorticity, magnitude, "vorticity");
 }

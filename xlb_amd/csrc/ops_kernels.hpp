@@ -333,6 +333,28 @@ __global__ void k_momentum_transfer(FieldView f0, FieldView bc, FieldView miss, 
   if (t < 3 && red[t][0] != 0.0) atomicAdd(force + t, red[t][0]);
 }
 
+// ---- GridToPoint (postprocess/grid_to_point.py:28-94): trilinear interpolation of component 0 at arbitrary points ----
+// weights in fp32 from the fp32 point coordinates, as the reference computes them; products and the 8-term sum in its order
+template <class T>
+__global__ void k_grid_to_point(FieldView g, Dims d, const float* pts /*[n][3]*/, T* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+  const int x = (int)px, y = (int)py, z = (int)pz;
+  const float dx = px - (float)x, dy = py - (float)y, dz = pz - (float)z;
+  const float one = 1.0f;
+  auto G = [&](int a, int b, int c) { return load_rt<T>(g, cell_index(g, d, x + a, y + b, z + c)); };
+  T v = T((one - dx) * (one - dy) * (one - dz)) * G(0, 0, 0);
+  v = v + T((one - dx) * (one - dy) * dz) * G(0, 0, 1);
+  v = v + T((one - dx) * dy * (one - dz)) * G(0, 1, 0);
+  v = v + T((one - dx) * dy * dz) * G(0, 1, 1);
+  v = v + T(dx * (one - dy) * (one - dz)) * G(1, 0, 0);
+  v = v + T(dx * (one - dy) * dz) * G(1, 0, 1);
+  v = v + T(dx * dy * (one - dz)) * G(1, 1, 0);
+  v = v + T(dx * dy * dz) * G(1, 1, 1);
+  out[i] = v;
+}
+
 // ---- ExtrapolationOutflowBC: auxiliary data after the collision --------------------------
 // Post-stream populations of ONE cell: periodic pull + the STREAMING-step boundary condition of that cell
 // (nse_stepper.py:246-257).  Generic slow path: only the outflow cells and the cells behind them run it.

@@ -5,6 +5,8 @@ NotImplementedError — with the out-of-place call style ``op(u, bc_mask, out_a,
 3-D fields.  Cells one layer inside the box whose six face neighbours carry no boundary id are written; the
 outputs keep their previous contents everywhere else (create them zero-filled, as the reference's callers do)."""
 
+import numpy as np
+
 from ... import _lib
 from ...compute_backend import ComputeBackend
 from ..operator import Operator
@@ -28,3 +30,20 @@ class QCriterion(Operator):
     def hip_implementation(self, u, bc_mask, norm_mu, q):
         _lib.check(_lib.load().xlbhip_q_criterion(self._ctx.handle, u.handle, bc_mask.handle, norm_mu.handle, q.handle))
         return norm_mu, q
+
+
+class GridToPoint(Operator):
+    """``GridToPoint()(grid, points, point_values) -> point_values``: trilinear interpolation of component 0 of a 3-D field
+    at arbitrary points (grid_to_point.py:28-104).  ``points`` is an ``(n, 3)`` float32 array in cell units,
+    ``point_values`` an ``(n,)`` array of the field's dtype that receives the result (host arrays: probes are few)."""
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, grid, points, point_values):
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must have shape (n, 3)")
+        if not (isinstance(point_values, np.ndarray) and point_values.flags.c_contiguous and point_values.shape == (pts.shape[0],) and point_values.dtype == grid.dtype):
+            raise ValueError("point_values must be a contiguous (n,) array of the field's dtype")
+        _lib.check(_lib.load().xlbhip_grid_to_point(self._ctx.handle, grid.handle, int(pts.shape[0]), pts.ctypes.data, point_values.ctypes.data))
+        return point_values
+
