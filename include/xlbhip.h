@@ -175,6 +175,14 @@ int xlbhip_build_masks(xlbhip_ctx* ctx, int lattice, int n_bc, const int32_t* bc
                        const int64_t* tag_count, const int32_t* const* solid_idx, const int64_t* solid_count,
                        const int32_t global_shape[3], int x_offset, xlbhip_field* bc_mask, xlbhip_field* missing_mask);
 
+/* MeshMaskerAABB()(bc, f_1, bc_mask, missing_mask): boundary_masker/aabb.py:38-100 + mesh_boundary_masker.py:62-245.
+ * vertices = n_triangles x 3 corners x (x, y, z) in lattice units (voxel i spans [i, i+1]), fully inside the domain.
+ * Voxels the surface passes through become BC_SOLID (255); fluid voxels next to one get bc_id and the missing bits of the
+ * directions pulled out of it; voxels of bc_id also miss the directions pulled from outside the box.  Existing mask
+ * contents are kept (other BCs' ids, earlier solid voxels).  Single-rank fields.  Synchronous. */
+int xlbhip_mesh_mask_aabb(xlbhip_ctx* ctx, int lattice, int bc_id, int64_t n_triangles, const float* vertices, xlbhip_field* bc_mask,
+                          xlbhip_field* missing_mask);
+
 /* ---- the stepper (the hot path) ------------------------------------------ */
 /* replaces: IncompressibleNavierStokesStepper._construct_warp + launch,
  * nse_stepper.py:335-476, with the JAX step order of :237-282. */

@@ -745,3 +745,94 @@ def grid_to_point(grid, points):
     v = v + (dx * dy * dz).astype(T) * g(1, 1, 1)
     return v
 
+
+# ---- MeshMaskerAABB (boundary_masker/aabb.py:38-100, mesh_boundary_masker.py:62-181) ---------------------------------
+BC_SOLID = 255
+
+
+def _tri_box_setup(v):
+    """Schwarz & Seidel (2010) triangle / unit-box overlap, the precomputation of mesh_boundary_masker.py:62-93; fp32."""
+    F = np.float32
+    v = v.astype(F)
+    e = np.stack([v[1] - v[0], v[2] - v[1], v[0] - v[2]])
+    m = -e[2]
+    n = np.array([e[0][1] * m[2] - e[0][2] * m[1], e[0][2] * m[0] - e[0][0] * m[2], e[0][0] * m[1] - e[0][1] * m[0]], dtype=F)
+    ln = np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+    if not ln > 0:
+        return None
+    n = (n / ln).astype(F)
+    c = (n > 0).astype(F)
+    d1 = n[0] * (c[0] - v[0][0]) + n[1] * (c[1] - v[0][1]) + n[2] * (c[2] - v[0][2])
+    d2 = n[0] * ((F(1) - c[0]) - v[0][0]) + n[1] * ((F(1) - c[1]) - v[0][1]) + n[2] * ((F(1) - c[2]) - v[0][2])
+    ne = np.zeros((3, 3, 2), F)
+    de = np.zeros((3, 3), F)
+    for ax0 in range(3):
+        ax1, ax2 = (ax0 + 1) % 3, (ax0 + 2) % 3
+        sgn = F(-1.0) if n[ax2] < 0 else F(1.0)
+        for i in range(3):
+            a0, a1 = -sgn * e[i][ax1], sgn * e[i][ax0]
+            ne[ax0, i] = (a0, a1)
+            de[ax0, i] = -(a0 * v[i][ax0] + a1 * v[i][ax1]) + max(F(0), a0) + max(F(0), a1)
+    return n, F(d1), F(d2), ne, de
+
+
+def _tri_box_overlap(t, low):
+    n, d1, d2, ne, de = t
+    F = np.float32
+    low = np.asarray(low, F)
+    npv = n[0] * low[0] + n[1] * low[1] + n[2] * low[2]
+    if not (npv + d1) * (npv + d2) <= 0:
+        return False
+    for ax0 in range(3):
+        ax1 = (ax0 + 1) % 3
+        for i in range(3):
+            if not ne[ax0, i, 0] * low[ax0] + ne[ax0, i, 1] * low[ax1] + de[ax0, i] >= 0:
+                return False
+    return True
+
+
+def mesh_mask_aabb(shape, lat, bc_id, vertices, bc_mask, missing_mask):
+    """MeshMaskerAABB on a (3 n_triangles, 3) triangle soup; returns updated copies of (bc_mask, missing_mask)."""
+    verts = np.asarray(vertices, np.float32).reshape(-1, 3, 3)
+    solid = np.zeros(shape, bool)
+    for v in verts:
+        t = _tri_box_setup(v)
+        if t is None:
+            continue
+        lo = np.maximum(np.floor(v.min(axis=0)).astype(int) - 1, 0)
+        hi = np.minimum(np.floor(v.max(axis=0)).astype(int), np.array(shape) - 1)
+        for i in range(lo[0], hi[0] + 1):
+            for j in range(lo[1], hi[1] + 1):
+                for k in range(lo[2], hi[2] + 1):
+                    if not solid[i, j, k] and _tri_box_overlap(t, (i, j, k)):
+                        solid[i, j, k] = True
+    bc = bc_mask.copy()
+    mm = missing_mask.astype(bool).copy()
+    was_solid = bc[0] == BC_SOLID
+    now_solid = was_solid | solid
+    nb = np.zeros((lat.q,) + tuple(shape), bool)  # nb[l]: the neighbour at +c_l is a mesh voxel
+    pad = np.pad(solid, 1)
+    for l in range(lat.q):
+        if l == lat.opp[l]:
+            continue
+        cx, cy, cz = (int(v) for v in lat.c[:, l])
+        nb[l] = pad[1 + cx : 1 + cx + shape[0], 1 + cy : 1 + cy + shape[1], 1 + cz : 1 + cz + shape[2]]
+    boundary = nb.any(axis=0) & ~now_solid
+    bc[0][now_solid] = BC_SOLID
+    bc[0][boundary] = bc_id
+    for l in range(lat.q):
+        if l != lat.opp[l]:
+            mm[lat.opp[l]] |= nb[l] & ~now_solid
+    # resolve_out_of_bound_kernel: voxels of this id miss the directions pulled from outside the box
+    idx = np.indices(shape)
+    has_id = bc[0] == bc_id
+    for l in range(lat.q):
+        if l == lat.opp[l]:
+            continue
+        outside = np.zeros(shape, bool)
+        for a in range(3):
+            p = idx[a] - int(lat.c[a, l])
+            outside |= (p < 0) | (p >= shape[a])
+        mm[l] |= has_id & outside
+    return bc, mm
+

@@ -494,6 +494,106 @@ __global__ void k_copy(const V* __restrict__ src, V* __restrict__ dst, size_t n)
   if (i < n) __builtin_nontemporal_store(src[i], dst + i);
 }
 
+// ---- MeshMaskerAABB (boundary_masker/aabb.py:38-100, mesh_boundary_masker.py:62-181): surface voxelisation of a
+// triangle mesh with the triangle / unit-box overlap test of Schwarz & Seidel (2010): the box straddles the triangle's
+// plane AND its projection overlaps the triangle's projection on the xy, yz and zx planes.  fp32 throughout.
+struct TriBox {
+  float n[3], d1, d2;       // unit normal, plane offsets of the two critical box corners
+  float ne[3][3][2], de[3][3];  // per projection axis-pair [ax] and edge [i]: 2-D edge normal and offset
+};
+__device__ inline bool tri_box_setup(const float* v /*[3][3]*/, TriBox& t) {
+  float e[3][3];
+  for (int a = 0; a < 3; ++a) {
+    e[0][a] = v[3 + a] - v[a];
+    e[1][a] = v[6 + a] - v[3 + a];
+    e[2][a] = v[a] - v[6 + a];
+  }
+  float nx = e[0][1] * (-e[2][2]) - e[0][2] * (-e[2][1]);  // (v1 - v0) x (v2 - v0), v2 - v0 = -e[2]
+  float ny = e[0][2] * (-e[2][0]) - e[0][0] * (-e[2][2]);
+  float nz = e[0][0] * (-e[2][1]) - e[0][1] * (-e[2][0]);
+  const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+  if (!(len > 0.0f)) return false;  // degenerate triangle: never intersects (mesh_boundary_masker.py:121)
+  t.n[0] = nx / len;
+  t.n[1] = ny / len;
+  t.n[2] = nz / len;
+  float c[3];
+  for (int a = 0; a < 3; ++a) c[a] = t.n[a] > 0.0f ? 1.0f : 0.0f;
+  t.d1 = t.n[0] * (c[0] - v[0]) + t.n[1] * (c[1] - v[1]) + t.n[2] * (c[2] - v[2]);
+  t.d2 = t.n[0] * ((1.0f - c[0]) - v[0]) + t.n[1] * ((1.0f - c[1]) - v[1]) + t.n[2] * ((1.0f - c[2]) - v[2]);
+  for (int ax0 = 0; ax0 < 3; ++ax0) {
+    const int ax1 = (ax0 + 1) % 3, ax2 = (ax0 + 2) % 3;
+    const float sgn = t.n[ax2] < 0.0f ? -1.0f : 1.0f;
+    for (int i = 0; i < 3; ++i) {
+      const float a0 = -sgn * e[i][ax1], a1 = sgn * e[i][ax0];
+      t.ne[ax0][i][0] = a0;
+      t.ne[ax0][i][1] = a1;
+      t.de[ax0][i] = -(a0 * v[3 * i + ax0] + a1 * v[3 * i + ax1]) + fmaxf(0.0f, a0) + fmaxf(0.0f, a1);
+    }
+  }
+  return true;
+}
+__device__ inline bool tri_box_overlap(const TriBox& t, float lx, float ly, float lz) {
+  const float low[3] = {lx, ly, lz};
+  const float np = t.n[0] * lx + t.n[1] * ly + t.n[2] * lz;
+  if (!((np + t.d1) * (np + t.d2) <= 0.0f)) return false;
+  for (int ax0 = 0; ax0 < 3; ++ax0) {
+    const int ax1 = (ax0 + 1) % 3;
+    for (int i = 0; i < 3; ++i)
+      if (!(t.ne[ax0][i][0] * low[ax0] + t.ne[ax0][i][1] * low[ax1] + t.de[ax0][i] >= 0.0f)) return false;
+  }
+  return true;
+}
+// one thread per triangle: every unit voxel [i, i+1]^3 its bounding box touches is tested, hits are marked solid
+__global__ void k_mesh_solid(const float* verts /*[n_tri][3][3]*/, int64_t n_tri, uint8_t* solid, int nx, int ny, int nz) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  TriBox t;
+  if (!tri_box_setup(v, t)) return;
+  int lo[3], hi[3];
+  const int ext[3] = {nx, ny, nz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 1);
+    hi[a] = min(ext[a] - 1, (int)floorf(mx));
+  }
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k)
+        if (tri_box_overlap(t, (float)i, (float)j, (float)k)) solid[((size_t)i * ny + j) * nz + k] = 1;
+}
+// per voxel (aabb.py:57-79 + resolve_out_of_bound_kernel): solid voxels get BC_SOLID (255); a fluid voxel with a solid
+// neighbour at +c_l gets the BC id and missing[opp l]; voxels of this id also miss every direction pulled from outside the box
+template <class L>
+__global__ void k_mesh_classify(const uint8_t* solid, uint8_t* bc, uint32_t* miss, Dims d, int id) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t c = ((size_t)x * d.ny + y) * d.nz + z;
+  if (bc[c] == 255 || solid[c]) {
+    bc[c] = 255;
+    return;
+  }
+  unsigned bits = 0;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l != opp<L>(l)) {  // every direction but the rest one
+      const int xn = x + L::c(0, l), yn = y + L::c(1, l), zn = z + L::c(2, l);
+      if (xn >= 0 && xn < d.nx && yn >= 0 && yn < d.ny && zn >= 0 && zn < d.nz && solid[((size_t)xn * d.ny + yn) * d.nz + zn]) bits |= 1u << opp<L>(l);
+    }
+  });
+  if (bits != 0u) bc[c] = (uint8_t)id;
+  if (bc[c] == id) {
+    static_for<L::Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      if constexpr (l != opp<L>(l)) {
+        const int xp = x - L::c(0, l), yp = y - L::c(1, l), zp = z - L::c(2, l);
+        if (xp < 0 || xp >= d.nx || yp < 0 || yp >= d.ny || zp < 0 || zp >= d.nz) bits |= 1u << l;
+      }
+    });
+  }
+  if (bits != 0u) miss[c] |= bits;
+}
+
 // meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table:
 //   bits 0-3 kind (0 fluid, XLBHIP_BC_* for the basic kinds, 9 = halfway wall WITH a moving-wall term),
 //   bits 4-7 slot of the BC in the stepper's packed tables, bits 8.. missing bit-set (D3Q19: 19 bits)

@@ -71,9 +71,14 @@ class BoundaryCondition(Operator):
         self.id = boundary_condition_registry.register_boundary_condition(f"{self.__class__.__name__}_{id(self)}")
         super().__init__(velocity_set, precision_policy, compute_backend)
         if mesh_vertices is not None:
-            raise NotImplementedError("mesh-based boundary conditions are out of scope of the HIP backend (SURVEY.md section 8)")
+            # triangle soup in lattice units, (3 n_triangles, d) — consumed by MeshMaskerAABB (boundary_masker/mesh_boundary_masker.py)
+            if indices is not None:
+                raise ValueError("give either indices or mesh_vertices")
+            mesh_vertices = np.asarray(mesh_vertices, dtype=np.float32)
+            if mesh_vertices.ndim != 2 or mesh_vertices.shape[1] != 3 or mesh_vertices.shape[0] % 3 != 0:
+                raise ValueError("Mesh points must be reshaped into an array (N, 3) where N indicates number of points (three per triangle)!")
         self.indices = indices
-        self.mesh_vertices = None
+        self.mesh_vertices = mesh_vertices
         self.voxelization_method = voxelization_method
         self.implementation_step = implementation_step
         self.needs_padding = False

@@ -1,3 +1,8 @@
-"""Boundary maskers of the HIP backend (index lists only; mesh voxelisation is out of scope)."""
+"""Boundary maskers of the HIP backend: index lists, and AABB voxelisation of a triangle mesh."""
 
 from .indices_boundary_masker import IndicesBoundaryMasker as IndicesBoundaryMasker
+from .mesh_boundary_masker import (
+    MeshMaskerAABB as MeshMaskerAABB,
+    MeshVoxelizationMethod as MeshVoxelizationMethod,
+    BC_SOLID as BC_SOLID,
+)

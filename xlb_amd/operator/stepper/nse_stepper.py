@@ -98,6 +98,17 @@ class IncompressibleNavierStokesStepper(Stepper):
         with_indices = [bc for bc in boundary_conditions if getattr(bc, "indices", None) is not None]
         if with_indices:
             bc_mask, missing_mask = masker(with_indices, bc_mask, missing_mask)
+        # mesh-based BCs (nse_stepper.py:165-203 in the reference): AABB voxelisation only
+        for bc in boundary_conditions:
+            if getattr(bc, "mesh_vertices", None) is None:
+                continue
+            from ..boundary_masker import MeshMaskerAABB
+
+            method = getattr(bc, "voxelization_method", None)
+            if method is not None and getattr(method, "name", "AABB") != "AABB":
+                raise NotImplementedError(f"voxelization method {method.name}: only AABB is built on the HIP backend")
+            mesh_masker = MeshMaskerAABB(self.velocity_set, self.precision_policy, self.compute_backend)
+            f_1, bc_mask, missing_mask = mesh_masker(bc, f_1, bc_mask, missing_mask)
         return f_1, bc_mask, missing_mask
 
     @Operator.register_backend(ComputeBackend.HIP)
