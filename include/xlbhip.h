@@ -183,6 +183,12 @@ int xlbhip_build_masks(xlbhip_ctx* ctx, int lattice, int n_bc, const int32_t* bc
 int xlbhip_mesh_mask_aabb(xlbhip_ctx* ctx, int lattice, int bc_id, int64_t n_triangles, const float* vertices, xlbhip_field* bc_mask,
                           xlbhip_field* missing_mask);
 
+/* MeshMaskerRay()(bc, f_1, bc_mask, missing_mask): boundary_masker/ray.py:38-76 — a voxel whose lattice link along c_l
+ * (from the voxel centre, length |c_l|) crosses the surface gets bc_id and missing[opp l]; no solid voxels are marked.
+ * Same conventions as xlbhip_mesh_mask_aabb. */
+int xlbhip_mesh_mask_ray(xlbhip_ctx* ctx, int lattice, int bc_id, int64_t n_triangles, const float* vertices, xlbhip_field* bc_mask,
+                         xlbhip_field* missing_mask);
+
 /* ---- the stepper (the hot path) ------------------------------------------ */
 /* replaces: IncompressibleNavierStokesStepper._construct_warp + launch,
  * nse_stepper.py:335-476, with the JAX step order of :237-282. */

@@ -836,3 +836,61 @@ def mesh_mask_aabb(shape, lat, bc_id, vertices, bc_mask, missing_mask):
         mm[l] |= has_id & outside
     return bc, mm
 
+
+def _seg_tri_hit(v, p, dvec, max_t):
+    """Moeller-Trumbore, fp32, the operation order of ops_kernels.hpp: seg_tri_hit"""
+    F = np.float32
+    v = v.astype(F)
+    e1, e2 = v[1] - v[0], v[2] - v[0]
+    dx, dy, dz = (F(x) for x in dvec)
+    pv = np.array([dy * e2[2] - dz * e2[1], dz * e2[0] - dx * e2[2], dx * e2[1] - dy * e2[0]], F)
+    det = (e1[0] * pv[0] + e1[1] * pv[1]) + e1[2] * pv[2]
+    if abs(det) < F(1e-12):
+        return False
+    inv = F(1.0) / det
+    t = np.asarray(p, F) - v[0]
+    u = ((t[0] * pv[0] + t[1] * pv[1]) + t[2] * pv[2]) * inv
+    if u < 0 or u > 1:
+        return False
+    q = np.array([t[1] * e1[2] - t[2] * e1[1], t[2] * e1[0] - t[0] * e1[2], t[0] * e1[1] - t[1] * e1[0]], F)
+    w = ((dx * q[0] + dy * q[1]) + dz * q[2]) * inv
+    if w < 0 or u + w > 1:
+        return False
+    tt = ((e2[0] * q[0] + e2[1] * q[1]) + e2[2] * q[2]) * inv
+    return bool(tt >= 0 and tt <= F(max_t))
+
+
+def mesh_mask_ray(shape, lat, bc_id, vertices, bc_mask, missing_mask):
+    """MeshMaskerRay (boundary_masker/ray.py:38-76); returns updated copies of (bc_mask, missing_mask)."""
+    F = np.float32
+    verts = np.asarray(vertices, F).reshape(-1, 3, 3)
+    bc = bc_mask.copy()
+    mm = missing_mask.astype(bool).copy()
+    lens = {1: F(1.0), 2: F(1.41421356237309515), 3: F(1.73205080756887719)}
+    for v in verts:
+        lo = np.maximum(np.floor(v.min(axis=0)).astype(int) - 2, 0)
+        hi = np.minimum(np.floor(v.max(axis=0)).astype(int) + 1, np.array(shape) - 1)
+        for i in range(lo[0], hi[0] + 1):
+            for j in range(lo[1], hi[1] + 1):
+                for k in range(lo[2], hi[2] + 1):
+                    p = (F(i) + F(0.5), F(j) + F(0.5), F(k) + F(0.5))
+                    for l in range(lat.q):
+                        if l == lat.opp[l] or mm[lat.opp[l], i, j, k] and bc[0, i, j, k] == bc_id:
+                            continue
+                        c = lat.c[:, l].astype(int)
+                        ln = lens[int((c * c).sum())]
+                        if _seg_tri_hit(v, p, (F(c[0]) / ln, F(c[1]) / ln, F(c[2]) / ln), ln):
+                            bc[0, i, j, k] = bc_id
+                            mm[lat.opp[l], i, j, k] = True
+    idx = np.indices(shape)
+    has_id = bc[0] == bc_id
+    for l in range(lat.q):
+        if l == lat.opp[l]:
+            continue
+        outside = np.zeros(shape, bool)
+        for a in range(3):
+            pp = idx[a] - int(lat.c[a, l])
+            outside |= (pp < 0) | (pp >= shape[a])
+        mm[l] |= has_id & outside
+    return bc, mm
+

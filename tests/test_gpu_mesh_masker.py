@@ -92,3 +92,49 @@ def test_flow_past_a_mesh_sphere_vs_oracle():
     out = a.numpy()
     fluid = o_bm[0] != orc.BC_SOLID  # solid voxels are never read by anyone: their contents are unspecified
     assert np.array_equal(out[:, fluid], exp[:, fluid])
+
+
+@pytest.mark.parametrize("lattice", ["D3Q19", "D3Q27"])
+def test_ray_voxelisation_vs_oracle(lattice):
+    from xlb_amd.operator.boundary_masker import MeshMaskerRay
+
+    vs, pp = init_hip(lattice)
+    lat = orc.Lattice(lattice)
+    shape = (16, 15, 14)
+    grid, f_0, f_1, missing_mask, bc_mask = create_nse_fields(shape)
+    verts = icosphere((7.3, 7.6, 6.9), 3.4, 1)
+    bc = HalfwayBounceBackBC(mesh_vertices=verts, voxelization_method=MeshVoxelizationMethod("RAY"))
+    _, bc_mask, missing_mask = MeshMaskerRay()(bc, f_1, bc_mask, missing_mask)
+    e_bc, e_mm = orc.mesh_mask_ray(shape, lat, bc.id, verts, np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool))
+    got_bc, got_mm = bc_mask.numpy(), missing_mask.numpy()
+    assert np.array_equal(got_bc, e_bc) and np.array_equal(got_mm, e_mm.astype(np.uint8))
+    assert int((got_bc == BC_SOLID).sum()) == 0 and int((got_bc == bc.id).sum()) > 100
+    # links are symmetric: if x misses opp(l) because the link x -> x + c_l crosses the surface, x + c_l misses l
+    x, y, z = np.where(got_bc[0] == bc.id)
+    for l in range(lat.q):
+        if l == lat.opp[l]:
+            continue
+        sel = got_mm[lat.opp[l], x, y, z] == 1
+        xn, yn, zn = x[sel] + lat.c[0, l], y[sel] + lat.c[1, l], z[sel] + lat.c[2, l]
+        assert np.all(got_mm[l, xn, yn, zn] == 1)
+
+
+def test_stepper_routes_ray_method():
+    shape = (20, 12, 12)
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    grid = grid_factory(shape)
+    verts = icosphere((8.4, 5.7, 6.2), 2.4, 1)
+    b_s = HalfwayBounceBackBC(mesh_vertices=verts, voxelization_method=MeshVoxelizationMethod("RAY"))
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_s])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    o_bm, o_mm = orc.mesh_mask_ray(shape, lat, b_s.id, verts, np.zeros((1,) + shape, np.uint8), np.zeros((19,) + shape, bool))
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    f_np = orc.perturbed_init(shape, lat, seed=61)
+    f_0.assign(f_np)
+    a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, 15)
+    exp = orc.run(f_np, o_bm, o_mm, [orc.BC(orc.KIND_HALFWAY_BB, b_s.id, None)], 1.3, lat, 15)
+    assert np.array_equal(a.numpy(), exp)
+    with pytest.raises(Exception, match="AABB and RAY"):
+        bad = HalfwayBounceBackBC(mesh_vertices=verts, voxelization_method=MeshVoxelizationMethod("WINDING"))
+        IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[bad]).prepare_fields()

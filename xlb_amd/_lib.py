@@ -66,6 +66,7 @@ SIGNATURES = {
     "xlbhip_second_moment": [_p, _i, _i, _p, _p],
     "xlbhip_vorticity": [_p, _p, _p, _p, _p],
     "xlbhip_mesh_mask_aabb": [_p, _i, _i, _i64, _p, _p, _p],
+    "xlbhip_mesh_mask_ray": [_p, _i, _i, _i64, _p, _p, _p],
     "xlbhip_grid_to_point": [_p, _p, _i64, _p, _p],
     "xlbhip_momentum_transfer": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, C.POINTER(C.c_double)],
     "xlbhip_stepper_set_bc_profile": [_p, _i, _i64, _p, _p],

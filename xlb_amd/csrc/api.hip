@@ -749,6 +749,48 @@ extern "C" int xlbhip_mesh_mask_aabb(xlbhip_ctx* c, int lattice, int bc_id, int6
   return rc;
 }
 
+extern "C" int xlbhip_mesh_mask_ray(xlbhip_ctx* c, int lattice, int bc_id, int64_t n_triangles, const float* vertices, xlbhip_field* bcm,
+                                    xlbhip_field* miss) {
+  XLB_REQUIRE(c && bcm && miss && (n_triangles == 0 || vertices), "mesh masker: null argument");
+  XLB_REQUIRE(lattice == XLBHIP_D3Q19 || lattice == XLBHIP_D3Q27, "MeshBoundaryMasker is only implemented for 3D velocity sets!");
+  XLB_REQUIRE(bcm->dtype == XLBHIP_U8 && bcm->card == 1 && bcm->halo == 0, "mesh masker: bc_mask must be a (1, nx, ny, nz) uint8 field without ghost planes");
+  XLB_REQUIRE(miss->dtype == XLBHIP_MISSING && miss->card == lattice_q(lattice) && same_grid(miss, bcm) && miss->halo == 0, "mesh masker: bad missing_mask field");
+  XLB_REQUIRE(bc_id >= 1 && bc_id <= 254, "bc id %d out of range 1..254", bc_id);
+  for (int64_t i = 0; i < n_triangles * 3; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float p = vertices[3 * i + a];
+      const int ext = a == 0 ? bcm->nx : (a == 1 ? bcm->ny : bcm->nz);
+      XLB_REQUIRE(p >= 0.0f && p < (float)ext, "Mesh extents exceed domain dimensions (%d,%d,%d). The mesh must be fully contained within the domain.",
+                  bcm->nx, bcm->ny, bcm->nz);
+    }
+  hipStream_t st = c->stream;
+  float* dv = nullptr;
+  hipError_t e = hipSuccess;
+  int rc = 0;
+  if (n_triangles > 0) {
+    XLB_HIP(hipMalloc(&dv, (size_t)n_triangles * 9 * sizeof(float)));
+    e = hipMemcpyAsync(dv, vertices, (size_t)n_triangles * 9 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+      rc = by_lattice(lattice, [&](auto L) {
+        hipLaunchKernelGGL(k_mesh_ray<decltype(L)>, blocks_for((size_t)n_triangles), 256, 0, st, dv, n_triangles, static_cast<uint8_t*>(bcm->data),
+                           static_cast<uint32_t*>(miss->data), dims(bcm), bc_id);
+        XLB_HIP(hipGetLastError());
+        return 0;
+      });
+  }
+  if (e == hipSuccess && rc == 0)
+    rc = by_lattice(lattice, [&](auto L) {
+      hipLaunchKernelGGL(k_mesh_resolve<decltype(L)>, blocks_for(bcm->cells()), 256, 0, st, static_cast<const uint8_t*>(bcm->data),
+                         static_cast<uint32_t*>(miss->data), dims(bcm), bc_id);
+      XLB_HIP(hipGetLastError());
+      return 0;
+    });
+  (void)hipStreamSynchronize(st);
+  if (dv) (void)hipFree(dv);
+  XLB_REQUIRE(e == hipSuccess, "mesh masker: %s", hipGetErrorString(e));
+  return rc;
+}
+
 // ---- stepper --------------------------------------------------------------------------------
 struct xlbhip_stepper {
   xlbhip_ctx* ctx = nullptr;

@@ -594,6 +594,75 @@ __global__ void k_mesh_classify(const uint8_t* solid, uint8_t* bc, uint32_t* mis
   if (bits != 0u) miss[c] |= bits;
 }
 
+// ---- MeshMaskerRay (boundary_masker/ray.py:38-76): a voxel whose link along c_l (from its centre, length |c_l|) crosses the
+// surface gets the BC id and missing[opp l].  One thread per triangle over the voxels around its bounding box; the
+// segment / triangle test is Moeller-Trumbore in fp32 (both faces count, like a mesh ray query).
+__device__ inline bool seg_tri_hit(const float* v, float px, float py, float pz, float dx, float dy, float dz, float max_t) {
+  const float e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
+  const float e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
+  const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+  const float det = (e1x * pvx + e1y * pvy) + e1z * pvz;
+  if (fabsf(det) < 1e-12f) return false;
+  const float inv = 1.0f / det;
+  const float tx = px - v[0], ty = py - v[1], tz = pz - v[2];
+  const float u = ((tx * pvx + ty * pvy) + tz * pvz) * inv;
+  if (u < 0.0f || u > 1.0f) return false;
+  const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+  const float w = ((dx * qx + dy * qy) + dz * qz) * inv;
+  if (w < 0.0f || u + w > 1.0f) return false;
+  const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+  return t >= 0.0f && t <= max_t;
+}
+template <class L>
+__global__ void k_mesh_ray(const float* verts, int64_t n_tri, uint8_t* bc, uint32_t* miss, Dims d, int id) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  int lo[3], hi[3];
+  const int ext[3] = {d.nx, d.ny, d.nz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 2);  // centre i + 0.5 within one link (<= 1 per axis) of the bounding box
+    hi[a] = min(ext[a] - 1, (int)floorf(mx) + 1);
+  }
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k) {
+        const float px = (float)i + 0.5f, py = (float)j + 0.5f, pz = (float)k + 0.5f;
+        unsigned bits = 0;
+        static_for<L::Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (l != opp<L>(l)) {
+            constexpr int n2 = L::c(0, l) * L::c(0, l) + L::c(1, l) * L::c(1, l) + L::c(2, l) * L::c(2, l);
+            const float len = n2 == 1 ? 1.0f : (n2 == 2 ? 1.41421356237309515f : 1.73205080756887719f);
+            if (seg_tri_hit(v, px, py, pz, (float)L::c(0, l) / len, (float)L::c(1, l) / len, (float)L::c(2, l) / len, len)) bits |= 1u << opp<L>(l);
+          }
+        });
+        if (bits != 0u) {
+          const size_t c = ((size_t)i * d.ny + j) * d.nz + k;
+          bc[c] = (uint8_t)id;
+          atomicOr(miss + c, bits);
+        }
+      }
+}
+// resolve_out_of_bound_kernel (mesh_boundary_masker.py:156-176): voxels of this id miss the directions pulled from outside the box
+template <class L>
+__global__ void k_mesh_resolve(const uint8_t* bc, uint32_t* miss, Dims d, int id) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t c = ((size_t)x * d.ny + y) * d.nz + z;
+  if (bc[c] != id) return;
+  unsigned bits = 0;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l != opp<L>(l)) {
+      const int xp = x - L::c(0, l), yp = y - L::c(1, l), zp = z - L::c(2, l);
+      if (xp < 0 || xp >= d.nx || yp < 0 || yp >= d.ny || zp < 0 || zp >= d.nz) bits |= 1u << l;
+    }
+  });
+  if (bits != 0u) miss[c] |= bits;
+}
+
 // meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table:
 //   bits 0-3 kind (0 fluid, XLBHIP_BC_* for the basic kinds, 9 = halfway wall WITH a moving-wall term),
 //   bits 4-7 slot of the BC in the stepper's packed tables, bits 8.. missing bit-set (D3Q19: 19 bits)

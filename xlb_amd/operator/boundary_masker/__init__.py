@@ -3,6 +3,7 @@
 from .indices_boundary_masker import IndicesBoundaryMasker as IndicesBoundaryMasker
 from .mesh_boundary_masker import (
     MeshMaskerAABB as MeshMaskerAABB,
+    MeshMaskerRay as MeshMaskerRay,
     MeshVoxelizationMethod as MeshVoxelizationMethod,
     BC_SOLID as BC_SOLID,
 )

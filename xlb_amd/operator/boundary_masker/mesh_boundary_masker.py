@@ -4,7 +4,8 @@ its kernel backends only, with the call ``masker(bc, f_1, bc_mask, missing_mask)
 
 ``bc.mesh_vertices``: triangle soup, ``(3 n_triangles, 3)`` in lattice units (voxel ``i`` spans ``[i, i+1]``), inside the
 domain.  Voxels the surface passes through become ``BC_SOLID`` (255), fluid voxels next to one get the BC's id and the
-missing bits of the directions pulled out of the solid.  The RAY / WINDING / AABB_CLOSE methods are not built."""
+missing bits of the directions pulled out of the solid (AABB); or the voxels whose lattice links cross the surface get them
+(RAY).  The WINDING / AABB_CLOSE methods are not built."""
 
 from dataclasses import dataclass, field
 
@@ -30,13 +31,14 @@ def MeshVoxelizationMethod(name, **options):
     return VoxelizationMethod(METHODS[name], name, options)
 
 
-class MeshMaskerAABB(Operator):
+class _MeshMasker(Operator):
+    _entry = None  # name of the C entry point
+
     def __init__(self, velocity_set=None, precision_policy=None, compute_backend=None):
         super().__init__(velocity_set, precision_policy, compute_backend)
         assert self.velocity_set.d == 3, "MeshBoundaryMasker is only implemented for 3D velocity sets!"
 
-    @Operator.register_backend(ComputeBackend.HIP)
-    def hip_implementation(self, bc, distances, bc_mask, missing_mask):
+    def _mask(self, bc, distances, bc_mask, missing_mask):
         assert bc.mesh_vertices is not None, f'Please provide the mesh vertices for {bc.__class__.__name__} BC using keyword "mesh_vertices"!'
         assert bc.indices is None, f"Please use IndicesBoundaryMasker operator if {bc.__class__.__name__} is imposed on known indices of the grid!"
         if getattr(bc, "needs_mesh_distance", False):
@@ -49,9 +51,26 @@ class MeshMaskerAABB(Operator):
                 f"Mesh extents ({lo}, {hi}) exceed domain dimensions {grid_shape}. The mesh must be fully contained within the domain."
             )
         bc.__dict__["mesh_vertices"] = None  # consumed, like the reference (mesh_boundary_masker.py:204)
-        _lib.check(
-            _lib.load().xlbhip_mesh_mask_aabb(
-                self._ctx.handle, self.velocity_set.hip_id, int(bc.id), int(verts.shape[0] // 3), verts.ctypes.data, bc_mask.handle, missing_mask.handle
-            )
-        )
+        entry = getattr(_lib.load(), self._entry)
+        _lib.check(entry(self._ctx.handle, self.velocity_set.hip_id, int(bc.id), int(verts.shape[0] // 3), verts.ctypes.data, bc_mask.handle, missing_mask.handle))
         return distances, bc_mask, missing_mask
+
+
+class MeshMaskerAABB(_MeshMasker):
+    """Surface voxels (triangle / box overlap) become BC_SOLID, their fluid neighbours the boundary voxels (aabb.py:38-100)."""
+
+    _entry = "xlbhip_mesh_mask_aabb"
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, bc, distances, bc_mask, missing_mask):
+        return self._mask(bc, distances, bc_mask, missing_mask)
+
+
+class MeshMaskerRay(_MeshMasker):
+    """Voxels whose lattice links cross the surface are the boundary voxels; nothing is marked solid (ray.py:38-76)."""
+
+    _entry = "xlbhip_mesh_mask_ray"
+
+    @Operator.register_backend(ComputeBackend.HIP)
+    def hip_implementation(self, bc, distances, bc_mask, missing_mask):
+        return self._mask(bc, distances, bc_mask, missing_mask)

@@ -102,12 +102,14 @@ class IncompressibleNavierStokesStepper(Stepper):
         for bc in boundary_conditions:
             if getattr(bc, "mesh_vertices", None) is None:
                 continue
-            from ..boundary_masker import MeshMaskerAABB
+            from ..boundary_masker import MeshMaskerAABB, MeshMaskerRay
 
             method = getattr(bc, "voxelization_method", None)
-            if method is not None and getattr(method, "name", "AABB") != "AABB":
-                raise NotImplementedError(f"voxelization method {method.name}: only AABB is built on the HIP backend")
-            mesh_masker = MeshMaskerAABB(self.velocity_set, self.precision_policy, self.compute_backend)
+            name = "AABB" if method is None else getattr(method, "name", "AABB")
+            if name not in ("AABB", "RAY"):
+                raise NotImplementedError(f"voxelization method {name}: AABB and RAY are built on the HIP backend")
+            masker_cls = MeshMaskerAABB if name == "AABB" else MeshMaskerRay
+            mesh_masker = masker_cls(self.velocity_set, self.precision_policy, self.compute_backend)
             f_1, bc_mask, missing_mask = mesh_masker(bc, f_1, bc_mask, missing_mask)
         return f_1, bc_mask, missing_mask
 
