@@ -117,6 +117,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON of rank 0: everything else that writes to file descriptor 1 — the
+    # reference-style no-slip warning of HalfwayBounceBackBC, RCCL's version banner (C code) — is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import xlb_amd
     from xlb_amd import ComputeBackend, PrecisionPolicy
     from xlb_amd import distribute as xdist
@@ -240,7 +245,8 @@ def main():
     }
     if world == 1 and args.cpu_baseline_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def measured_traffic(args, world, kernel):
