@@ -955,13 +955,7 @@ static int launch_any(const xlbhip_stepper* s, const StepLaunch& p);
 // single-step kernel twice with a third population field holding their f(t+1).
 static int step_twice_edge_ext(xlbhip_stepper* s, StepLaunch p, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm,
                                const xlbhip_field* miss, double omega) {
-  xlbhip_ctx* c = s->ctx;
-  if (!s->scratch || s->scratch->nx != src->nx || s->scratch->ny != src->ny || s->scratch->nz != src->nz || s->scratch->dtype != src->dtype) {
-    if (s->scratch) xlbhip_field_destroy(s->scratch);
-    s->scratch = nullptr;
-    if (int rc = xlbhip_field_create(c, src->card, src->nx, src->ny, src->nz, src->dtype, src->halo, 0.0, &s->scratch)) return rc;
-    XLB_REQUIRE(s->scratch->plane_stride == src->plane_stride, "scratch field layout differs from the population fields");
-  }
+  XLB_REQUIRE(s->scratch && s->scratch->plane_stride == src->plane_stride, "scratch field missing (can_fuse2 allocates it)");
   const int nx = src->nx;
   p.x_begin = 2;
   p.x_count = nx - 4;
@@ -1041,6 +1035,18 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
       flag = 1;
     (void)hipFree(dflag);
     if (flag != 0) return false;
+    // the end planes need a third population field; without the memory for it the stepper stays on single steps
+    if (!s->scratch || s->scratch->nx != src->nx || s->scratch->ny != src->ny || s->scratch->nz != src->nz || s->scratch->dtype != src->dtype) {
+      if (s->scratch) xlbhip_field_destroy(s->scratch);
+      s->scratch = nullptr;
+      if (xlbhip_field_create(c, src->card, src->nx, src->ny, src->nz, src->dtype, src->halo, 0.0, &s->scratch) != 0 ||
+          s->scratch->plane_stride != src->plane_stride) {
+        if (s->scratch) xlbhip_field_destroy(s->scratch);
+        s->scratch = nullptr;
+        (void)hipGetLastError();
+        return false;
+      }
+    }
     s->edge_ext_ok = true;
   }
   StepLaunch p = make_launch(s, src, dst, bcm, miss, 1.0);
