@@ -22,15 +22,77 @@ class LatticeT(C.Structure):
 _lib = None
 
 
+def _open(path):
+    lib = C.CDLL(path)
+    lib.lbmref_run.restype = C.c_int
+    lib.lbmref_set_threads.restype = C.c_int
+    return lib
+
+
 def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not built: run `make oracle`")
-        _lib = C.CDLL(LIB_PATH)
-        _lib.lbmref_run.restype = C.c_int
-        _lib.lbmref_set_threads.restype = C.c_int
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+def _compile_here(src_name, out_stem, compiler, extra=()):
+    """Compile one file of this directory for THE HOST IT RUNS ON into oracle/_build/ (-march=native code must not
+    travel between machines: the directory is git- and gpurun-ignored); None when the compiler is unavailable."""
+    import subprocess
+
+    out_dir = os.path.join(_HERE, "_build")
+    out = os.path.join(out_dir, f"{out_stem}_{os.uname().nodename}.so")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        src = os.path.join(_HERE, src_name)
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.run([compiler, "-O3", "-march=native", "-fPIC", "-shared", "-fopenmp", *extra, "-o", out, src, "-lm"], check=True,
+                           capture_output=True, timeout=300)
+        return C.CDLL(out)
+    except Exception:
+        return None
+
+
+def build_fast():
+    """lbm_ref.c once more, tuned for this host (gcc -O3 -march=native, contraction allowed): NOT bit-exact; the generic
+    optimised-build leg of bench.py's CPU baseline (any lattice / collision)."""
+    lib = _compile_here("lbm_ref.c", "liblbmref_fast", "gcc")
+    if lib is not None:
+        lib.lbmref_run.restype = C.c_int
+        lib.lbmref_set_threads.restype = C.c_int
+    return lib
+
+
+def build_cpu_port():
+    """oracle/lbm_cpu_fast.cpp: the vectorised CPU port of the BGK step (SURVEY 8(d) optimised CPU baseline)."""
+    lib = _compile_here("lbm_cpu_fast.cpp", "liblbmcpufast", "g++", extra=("-std=c++17",))
+    if lib is not None:
+        lib.lbmfast_run.restype = C.c_int
+        lib.lbmfast_set_threads.restype = C.c_int
+    return lib
+
+
+def run_cpu_port(lib, f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, threads=0):
+    """n_steps of the vectorised CPU port (fp32, BGK, D3Q19 / D3Q27)."""
+    assert lat.q in (19, 27)
+    if threads:
+        lib.lbmfast_set_threads(int(threads))
+    a = np.ascontiguousarray(f_0, dtype=np.float32).copy()
+    b = np.empty_like(a)
+    nx, ny, nz = a.shape[1:]
+    ids, kinds, vals = bc_tables(bcs, lat, "FP32FP32")
+    bm = None if bc_mask is None or not len(bcs) else np.ascontiguousarray(bc_mask.reshape(-1), np.uint8)
+    mm = None if missing_mask is None or not len(bcs) else np.ascontiguousarray(missing_mask, np.uint8)
+    rc = lib.lbmfast_run(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_void_p(bm.ctypes.data if bm is not None else None),
+                         C.c_void_p(mm.ctypes.data if mm is not None else None), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(lat.q),
+                         C.c_int(len(bcs)), C.c_void_p(ids.ctypes.data), C.c_void_p(kinds.ctypes.data), C.c_void_p(vals.ctypes.data),
+                         C.c_double(float(omega)), C.c_int(int(n_steps)))
+    if rc:
+        raise RuntimeError(f"lbmfast_run failed with code {rc}")
+    return a if n_steps % 2 == 0 else b
 
 
 def lattice_struct(lat):
@@ -65,16 +127,16 @@ def bc_tables(bcs, lat, policy):
     return ids, kinds, vals
 
 
-def set_threads(n):
-    return load().lbmref_set_threads(int(n))
+def set_threads(n, lib=None):
+    return (lib or load()).lbmref_set_threads(int(n))
 
 
-def run(f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, policy="FP32FP32", collision="BGK", threads=0):
-    """n_steps of the C restatement; compute == store precision only (FP32FP32 / FP64FP64)."""
+def run(f_0, bc_mask, missing_mask, bcs, omega, lat, n_steps, policy="FP32FP32", collision="BGK", threads=0, lib=None):
+    """n_steps of the C restatement; compute == store precision only (FP32FP32 / FP64FP64).  `lib`: a build_fast() handle."""
     assert policy in ("FP32FP32", "FP64FP64")
-    lib = load()
+    lib = lib or load()
     if threads:
-        set_threads(threads)
+        set_threads(threads, lib=lib)
     T = orc.compute_dtype(policy)
     a = np.ascontiguousarray(f_0, dtype=T).copy()
     b = np.empty_like(a)

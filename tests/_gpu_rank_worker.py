@@ -55,6 +55,30 @@ def main():
                 print(f"mismatch: {walls_cls.__name__} shape {shape} fuse2 {fuse2} overlap {overlap}", flush=True)
             ok &= good
             f_0.assign(f_np[:, x0 : x0 + nxl])
+    # uneven slabs on either side of the two-step kernel's chip-filling rule.  fuse2 = 1 with the rule
+    # scaled to a 2-CU chip: 64 planes -> 2 x-segments -> fills it -> eligible; 63 planes -> 1 segment -> half empty -> not.
+    # Pairs and single steps post different message sets, so the ranks must agree (MIN over the ranks) or the run hangs.
+    if world == 2:
+        ctx.set_option("fuse2", 1)
+        ctx.set_option("fuse2_cus", 2)
+        ctx.set_option("overlap", 1)
+        shape = (127, 8, 64)
+        grid, bcs, lat, obcs = hip_cavity_3d(shape, FullwayBounceBackBC)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        local = stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        votes = xdist.all_gather(bool(local))
+        good = votes == [True, False]
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        x0, nxl = grid.x_offset, grid.local_shape[0]
+        f_np = orc.perturbed_init(shape, lat, seed=11)
+        f_0.assign(f_np[:, x0 : x0 + nxl])
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.1, 5)
+        good &= bool(np.array_equal(xdist.gather_field(a), orc.run(f_np, o_bm, o_mm, obcs, 1.1, lat, 5)))
+        if not good and rank == 0:
+            print(f"mismatch: slabs straddling the fuse2 rule, votes {votes}", flush=True)
+        ok &= good
+        ctx.set_option("fuse2_cus", 0)
     # widened rows across a slab boundary: profile inlet on rank 0, extrapolation outflow on the last rank, a halfway
     # sphere given by interior indices that straddles the rank boundary, fullway walls (extended kernel variant,
     # k_outflow_aux, per-rank profile table, solid marks in the masker); force on the sphere summed over ranks

@@ -123,3 +123,23 @@ def test_sphere_channel_golden_pins_the_oracle():
     assert np.array_equal(orc.q_criterion(u, bc_mask, zero[:1], zero[:1])[1], g["q"])
     assert np.array_equal(orc.momentum_transfer(f, bcs[3], bc_mask, missing, lat), g["force"])
     assert g["force"][0] > 0  # drag
+
+
+def test_vectorised_cpu_port_matches_oracle():
+    """oracle/lbm_cpu_fast.cpp (bench.py's optimised CPU baseline, compiled on this host): same step as the NumPy oracle to
+    rounding (contraction and flush-to-zero allowed there: not bit-exact), every basic BC kind, D3Q19 and D3Q27."""
+    lib = lbm_ref.build_cpu_port()
+    if lib is None:
+        pytest.skip("g++ not available")
+    for kind in (orc.KIND_HALFWAY_BB, orc.KIND_FULLWAY_BB):
+        lat, shape, bcs = orc.cavity_3d(14, kind)
+        bm, mm = orc.build_masks(shape, lat, bcs)
+        f = orc.perturbed_init(shape, lat, seed=3)
+        exp = orc.run(f, bm, mm, bcs, 1.3, lat, 5)
+        got = lbm_ref.run_cpu_port(lib, f, bm, mm, bcs, 1.3, lat, 5, threads=2)
+        assert np.abs(got - exp).max() <= 1e-6
+    lat = orc.Lattice("D3Q27")
+    shape = (9, 7, 11)
+    f = orc.perturbed_init(shape, lat, seed=1)
+    bm, mm = orc.build_masks(shape, lat, [])
+    assert np.abs(lbm_ref.run_cpu_port(lib, f, None, None, [], 1.7, lat, 4) - orc.run(f, bm, mm, [], 1.7, lat, 4)).max() <= 1e-6

@@ -35,6 +35,11 @@ int lattice_d(int lattice) { return lattice == XLBHIP_D2Q9 ? 2 : 3; }
 
 static const size_t GUARD_BYTES = 256;
 
+// contents version of a field: globally unique, so a cache keyed on (field address, version) cannot be fooled by a
+// new field that recycles a freed one's address
+static uint64_t g_version = 0;
+static void touch(xlbhip_field* f) { f->version = ++g_version; }
+
 static FieldView view(const xlbhip_field* f) {
   FieldView v;
   v.data = f ? f->data : nullptr;
@@ -149,6 +154,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
+  c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
   return 0;
@@ -264,6 +270,7 @@ int xlbhip_field_destroy(xlbhip_field* f) {
 
 int xlbhip_field_fill(xlbhip_field* f, double v) {
   XLB_REQUIRE(f, "field is null");
+  touch(f);
   hipStream_t st = f->ctx->stream;
   if (v == 0.0) {
     XLB_HIP(hipMemsetAsync(f->base, 0, f->alloc_bytes, st));
@@ -287,6 +294,7 @@ int xlbhip_field_copy(xlbhip_field* dst, const xlbhip_field* src) {
   XLB_REQUIRE(dst->dtype == src->dtype && dst->card == src->card && same_grid(dst, src) && dst->halo == src->halo &&
                   dst->plane_stride == src->plane_stride,
               "field_copy: layouts differ");
+  touch(dst);
   XLB_HIP(hipMemcpyAsync(dst->base, src->base, src->alloc_bytes, hipMemcpyDeviceToDevice, dst->ctx->stream));
   return 0;
 }
@@ -297,6 +305,7 @@ int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int byt
   XLB_REQUIRE(bytes_per_lane == 4 || bytes_per_lane == 16, "bytes_per_lane must be 4 or 16");
   const size_t bytes = src->planes * src->plane_stride * dtype_size(src->dtype);
   XLB_REQUIRE(bytes % 16 == 0, "field size not a multiple of 16 bytes");
+  touch(dst);
   hipStream_t st = dst->ctx->stream;
   if (bytes_per_lane == 4) {
     const size_t n = bytes / 4;
@@ -324,6 +333,7 @@ int xlbhip_field_info(const xlbhip_field* f, int* card, int* nx, int* ny, int* n
 
 int xlbhip_field_upload(xlbhip_field* f, const void* host, size_t bytes) {
   XLB_REQUIRE(f && host, "null argument");
+  touch(f);
   hipStream_t st = f->ctx->stream;
   const size_t n = f->cells();
   if (f->dtype == XLBHIP_MISSING) {
@@ -393,6 +403,7 @@ int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane
               "plane (%d, %d) out of range", population, storage_plane);
   const size_t es = dtype_size(f->dtype), plane = (size_t)f->ny * f->nz;
   XLB_REQUIRE(bytes == plane * es, "plane size %zu != %zu", bytes, plane * es);
+  touch(f);
   char* d = static_cast<char*>(f->data) + ((size_t)population * f->plane_stride + (size_t)storage_plane * plane) * es;
   XLB_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, f->ctx->stream));
   XLB_HIP(hipStreamSynchronize(f->ctx->stream));
@@ -647,6 +658,8 @@ int xlbhip_build_masks(xlbhip_ctx* c, int lattice, int n_bc, const int32_t* ids,
   XLB_REQUIRE(gshape[1] == bcm->ny && gshape[2] == bcm->nz && x_offset >= 0 && x_offset + bcm->nx <= gshape[0],
               "slab (offset %d, nx %d) does not fit global shape (%d,%d,%d)", x_offset, bcm->nx, gshape[0], gshape[1], gshape[2]);
   XLB_REQUIRE(n_bc == 0 || (ids && tag_idx && tag_count), "null bc arrays");
+  touch(bcm);
+  touch(miss);
   hipStream_t st = c->stream;
   const Dims d = dims(bcm);
   const size_t plane = (size_t)d.ny * d.nz;
@@ -654,13 +667,25 @@ int xlbhip_build_masks(xlbhip_ctx* c, int lattice, int n_bc, const int32_t* ids,
   uint8_t* solid = nullptr;
   const size_t solid_bytes = (size_t)(d.nx + 2) * plane;
   XLB_HIP(hipMalloc(&solid, solid_bytes));
-  XLB_HIP(hipMemsetAsync(solid, 0, solid_bytes, st));
+  if (hipError_t e_ = hipMemsetAsync(solid, 0, solid_bytes, st); e_ != hipSuccess) {
+    (void)hipFree(solid);
+    XLB_FAIL("hipMemsetAsync failed: %s", hipGetErrorString(e_));
+  }
   std::vector<int32_t*> tmp;
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(st);
     for (auto p : tmp) (void)hipFree(p);
     (void)hipFree(solid);
   };
+  // every failure below releases the temporaries (the stream is drained first: copies may still read them)
+#define XLB_MASK_HIP(expr)                                                                                     \
+  do {                                                                                                         \
+    hipError_t e_ = (expr);                                                                                    \
+    if (e_ != hipSuccess) {                                                                                    \
+      cleanup();                                                                                               \
+      XLB_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    }                                                                                                          \
+  } while (0)
   uint8_t* bc_base = static_cast<uint8_t*>(bcm->data) + (size_t)bcm->halo * plane;  // interior plane 0
   for (int i = 0; i < n_bc; ++i) {
     if (ids[i] < 1 || ids[i] > 255) {
@@ -670,18 +695,18 @@ int xlbhip_build_masks(xlbhip_ctx* c, int lattice, int n_bc, const int32_t* ids,
     if (solid_idx && solid_idx[i] && solid_count && solid_count[i] > 0) {
       const int64_t n = solid_count[i];
       int32_t* dv = nullptr;
-      XLB_HIP(hipMalloc(&dv, (size_t)n * 3 * sizeof(int32_t)));
+      XLB_MASK_HIP(hipMalloc(&dv, (size_t)n * 3 * sizeof(int32_t)));
       tmp.push_back(dv);
-      XLB_HIP(hipMemcpyAsync(dv, solid_idx[i], (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      XLB_MASK_HIP(hipMemcpyAsync(dv, solid_idx[i], (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_scatter_u8, blocks_for((size_t)n), 256, 0, st, solid, dv, n, (uint8_t)1, x_offset - 1, x_offset + d.nx + 1,
                          d.ny, d.nz);
     }
     if (tag_count[i] > 0) {
       const int64_t n = tag_count[i];
       int32_t* dv = nullptr;
-      XLB_HIP(hipMalloc(&dv, (size_t)n * 3 * sizeof(int32_t)));
+      XLB_MASK_HIP(hipMalloc(&dv, (size_t)n * 3 * sizeof(int32_t)));
       tmp.push_back(dv);
-      XLB_HIP(hipMemcpyAsync(dv, tag_idx[i], (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      XLB_MASK_HIP(hipMemcpyAsync(dv, tag_idx[i], (size_t)n * 3 * sizeof(int32_t), hipMemcpyHostToDevice, st));
       hipLaunchKernelGGL(k_scatter_u8, blocks_for((size_t)n), 256, 0, st, bc_base, dv, n, (uint8_t)ids[i], x_offset, x_offset + d.nx, d.ny,
                          d.nz);
     }
@@ -689,9 +714,9 @@ int xlbhip_build_masks(xlbhip_ctx* c, int lattice, int n_bc, const int32_t* ids,
   // stream the (old | solid | outside) marks: missing'[l, x] = marks[l, x - c_l]
   uint32_t* old = nullptr;
   const size_t mbytes = miss->cells_with_halo() * sizeof(uint32_t);
-  XLB_HIP(hipMalloc(&old, mbytes));
+  XLB_MASK_HIP(hipMalloc(&old, mbytes));
   tmp.push_back(reinterpret_cast<int32_t*>(old));
-  XLB_HIP(hipMemcpyAsync(old, miss->data, mbytes, hipMemcpyDeviceToDevice, st));
+  XLB_MASK_HIP(hipMemcpyAsync(old, miss->data, mbytes, hipMemcpyDeviceToDevice, st));
   const size_t n = bcm->cells();
   int rc = by_lattice(lattice, [&](auto L) {
     hipLaunchKernelGGL(k_missing<decltype(L)>, blocks_for(n), 256, 0, st, (uint32_t*)miss->data, old, solid, d, miss->halo, gshape[0],
@@ -701,6 +726,7 @@ int xlbhip_build_masks(xlbhip_ctx* c, int lattice, int n_bc, const int32_t* ids,
   });
   cleanup();
   return rc;
+#undef XLB_MASK_HIP
 }
 
 }  // extern "C"
@@ -712,6 +738,8 @@ extern "C" int xlbhip_mesh_mask_aabb(xlbhip_ctx* c, int lattice, int bc_id, int6
   XLB_REQUIRE(bcm->dtype == XLBHIP_U8 && bcm->card == 1 && bcm->halo == 0, "mesh masker: bc_mask must be a (1, nx, ny, nz) uint8 field without ghost planes");
   XLB_REQUIRE(miss->dtype == XLBHIP_MISSING && miss->card == lattice_q(lattice) && same_grid(miss, bcm) && miss->halo == 0, "mesh masker: bad missing_mask field");
   XLB_REQUIRE(bc_id >= 1 && bc_id <= 254, "bc id %d out of range 1..254", bc_id);
+  touch(bcm);
+  touch(miss);
   // the mesh must lie inside the domain (mesh_boundary_masker.py:196-201)
   for (int64_t i = 0; i < n_triangles * 3; ++i)
     for (int a = 0; a < 3; ++a) {
@@ -756,6 +784,8 @@ extern "C" int xlbhip_mesh_mask_ray(xlbhip_ctx* c, int lattice, int bc_id, int64
   XLB_REQUIRE(bcm->dtype == XLBHIP_U8 && bcm->card == 1 && bcm->halo == 0, "mesh masker: bc_mask must be a (1, nx, ny, nz) uint8 field without ghost planes");
   XLB_REQUIRE(miss->dtype == XLBHIP_MISSING && miss->card == lattice_q(lattice) && same_grid(miss, bcm) && miss->halo == 0, "mesh masker: bad missing_mask field");
   XLB_REQUIRE(bc_id >= 1 && bc_id <= 254, "bc id %d out of range 1..254", bc_id);
+  touch(bcm);
+  touch(miss);
   for (int64_t i = 0; i < n_triangles * 3; ++i)
     for (int a = 0; a < 3; ++a) {
       const float p = vertices[3 * i + a];
@@ -804,6 +834,10 @@ struct xlbhip_stepper {
   xlbhip_field* scratch = nullptr;
   bool edge_ext_ok = false;
   bool has_edge_kinds = false;  // kinds the two-step kernel does not evaluate itself: Zou-He family, outflow, do-nothing
+  // result of the last "are all such cells in the x end planes" scan, valid for this (bc_mask field, contents version)
+  const xlbhip_field* scan_field = nullptr;
+  uint64_t scan_version = 0;
+  int scan_flag = 1;
   uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
   int order_ty = 0, order_tz = 0;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
@@ -908,6 +942,11 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
 // (320^3: 4 -> 8 segments = 3.1 -> 6.25 rounds, -9 %; 256^3: 2 segments = exactly one round).  With halfway walls the
 // hull tiles are the expensive ones and finer items balance them better: take the most segments of >= 32 planes
 // (measured at 256^3 ... 512^3: profiles/r01/sweeps.md).
+static long fill_cus(const xlbhip_ctx* c) {
+  const int64_t o = opt(c, "fuse2_cus", 0);
+  return o > 0 ? (long)o : (c->compute_units > 0 ? c->compute_units : 256);
+}
+
 static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
   const int64_t xseg = opt(s->ctx, "fuse2_xseg", 0);
   if (xseg > 0) {
@@ -915,7 +954,7 @@ static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
     while (n > 1 && p.x_count / n < 8) n /= 2;
     return n;
   }
-  const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
+  const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = fill_cus(s->ctx);
   int best = 1;
   long best_cost = -1;
   for (int n = 1; n <= 8; n *= 2) {
@@ -1026,15 +1065,20 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // Zou-He / Regularized / outflow / do-nothing cells: fine when they all sit in the two x end planes (scan of bc_mask, 1 B / cell)
     if (!bcm || src->halo != 0 || src->nx < 16 || s->lattice != XLBHIP_D3Q19) return false;
     xlbhip_ctx* c = s->ctx;
-    int* dflag = nullptr;
-    int flag = 1;
-    if (hipMalloc(&dflag, sizeof(int)) != hipSuccess) return false;
-    (void)hipMemsetAsync(dflag, 0, sizeof(int), c->stream);
-    hipLaunchKernelGGL(k_ext_interior_scan, blocks_for(bcm->cells()), 256, 0, c->stream, view(bcm), s->tab_kind, dims(bcm), dflag);
-    if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
-      flag = 1;
-    (void)hipFree(dflag);
-    if (flag != 0) return false;
+    if (s->scan_field != bcm || s->scan_version != bcm->version) {  // one scan per (stepper, bc_mask contents), not per run
+      int* dflag = nullptr;
+      int flag = 1;
+      if (hipMalloc(&dflag, sizeof(int)) != hipSuccess) return false;
+      (void)hipMemsetAsync(dflag, 0, sizeof(int), c->stream);
+      hipLaunchKernelGGL(k_ext_interior_scan, blocks_for(bcm->cells()), 256, 0, c->stream, view(bcm), s->tab_kind, dims(bcm), dflag);
+      if (hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        flag = 1;
+      (void)hipFree(dflag);
+      s->scan_field = bcm;
+      s->scan_version = bcm->version;
+      s->scan_flag = flag;
+    }
+    if (s->scan_flag != 0) return false;
     // the end planes need a third population field; without the memory for it the stepper stays on single steps
     if (!s->scratch || s->scratch->nx != src->nx || s->scratch->ny != src->ny || s->scratch->nz != src->nz || s->scratch->dtype != src->dtype) {
       if (s->scratch) xlbhip_field_destroy(s->scratch);
@@ -1054,7 +1098,7 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   if (mode == 1) {
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
-    const long items = (long)(p.ny / 8) * (p.nz / 64) * fuse2_segments(s, p), cus = s->ctx->compute_units > 0 ? s->ctx->compute_units : 256;
+    const long items = (long)(p.ny / 8) * (p.nz / 64) * fuse2_segments(s, p), cus = fill_cus(s->ctx);
     const long rounds = (items + cus - 1) / cus;
     if (items * 100 < rounds * cus * 85) return false;
     // halfway walls make the hull tiles ~1.5x as expensive as fluid tiles; when most tiles are hull tiles two single
@@ -1318,7 +1362,15 @@ static int run_steps(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const 
   xlbhip_field* oth = b;
   // (a host-staged transport refills the ghosts between calls: it drives pairs through xlbhip_step2 itself)
   const bool caller_fills_ghosts = a->halo > 0 && opt(s->ctx, "external_halo", 0) != 0;
-  if (n >= 2 && !caller_fills_ghosts && can_fuse2(s, a, b, bcm, miss)) {
+  bool fuse = n >= 2 && !caller_fills_ghosts && can_fuse2(s, a, b, bcm, miss);
+  if (n >= 2 && a->halo > 0 && !caller_fills_ghosts && comm_ranks(s->ctx) > 1) {
+    // pairs and single steps post different message sets (depth-2 / depth-1 exchange, meta planes): every rank must take
+    // the same decision, and uneven slabs may sit on either side of the chip-filling rule -> MIN over the ranks
+    int all = 0;
+    if (int rc = comm_all_min(s->ctx, fuse ? 1 : 0, &all)) return rc;
+    fuse = all != 0;
+  }
+  if (fuse) {
     if (int rc = prepare_fuse2(s, bcm, miss)) return rc;
     // choose the number of pairs so that the remaining single steps land the result in the right buffer:
     // after P pairs the data sits in (P odd ? b : a); then r = n - 2P single steps flip r more times.

@@ -23,6 +23,7 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -47,6 +48,7 @@ static int load_rccl() {
   XLB_SYM(GroupEnd, "ncclGroupEnd");
   XLB_SYM(Send, "ncclSend");
   XLB_SYM(Recv, "ncclRecv");
+  XLB_SYM(AllReduce, "ncclAllReduce");
   XLB_SYM(GetErrorString, "ncclGetErrorString");
 #undef XLB_SYM
   g_rccl.lib = lib;
@@ -62,6 +64,7 @@ static int load_rccl() {
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, n_ranks = 1, periodic = 1;
+  int* flag = nullptr;  // device scratch of comm_all_min
 };
 
 template <class L>
@@ -92,19 +95,44 @@ static int run_messages(xlbhip_ctx* c, const std::vector<HaloMsg>& msgs, size_t 
   const int rr = (r + 1) % n, lr = (r + n - 1) % n;
   const bool has_right = cm->periodic || r + 1 < n;
   const bool has_left = cm->periodic || r > 0;
+  if (!has_right && !has_left) return 0;
   XLB_NCCL(g_rccl.GroupStart());
+  // a failing call must not leave the group open (later RCCL calls of this thread would be queued into it silently)
+  ncclResult_t bad = ncclSuccess;
+  auto post = [&](ncclResult_t r) {
+    if (bad == ncclSuccess && r != ncclSuccess) bad = r;
+    return bad == ncclSuccess;
+  };
   for (const HaloMsg& m : msgs) {
     if (m.dir > 0) {
-      if (has_right) XLB_NCCL(g_rccl.Send(m.send, bytes, ncclInt8, rr, cm->comm, st));
-      if (has_left) XLB_NCCL(g_rccl.Recv(m.recv, bytes, ncclInt8, lr, cm->comm, st));
+      if (has_right && !post(g_rccl.Send(m.send, bytes, ncclInt8, rr, cm->comm, st))) break;
+      if (has_left && !post(g_rccl.Recv(m.recv, bytes, ncclInt8, lr, cm->comm, st))) break;
     } else {
-      if (has_left) XLB_NCCL(g_rccl.Send(m.send, bytes, ncclInt8, lr, cm->comm, st));
-      if (has_right) XLB_NCCL(g_rccl.Recv(m.recv, bytes, ncclInt8, rr, cm->comm, st));
+      if (has_left && !post(g_rccl.Send(m.send, bytes, ncclInt8, lr, cm->comm, st))) break;
+      if (has_right && !post(g_rccl.Recv(m.recv, bytes, ncclInt8, rr, cm->comm, st))) break;
     }
   }
-  XLB_NCCL(g_rccl.GroupEnd());
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) XLB_FAIL("ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(bad));
+  if (end != ncclSuccess) XLB_FAIL("ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
   return 0;
 }
+
+// MIN over the ranks of the communicator of a small host integer (a decision every rank must take alike, e.g. whether
+// xlbhip_run pairs its steps: the two protocols post different message sets).  Blocking; off the per-step path.
+int comm_all_min(xlbhip_ctx* c, int value, int* out) {
+  Comm* cm = c->comm;
+  *out = value;
+  if (!cm || !cm->comm || cm->n_ranks <= 1) return 0;
+  if (!cm->flag) XLB_HIP(hipMalloc(&cm->flag, 2 * sizeof(int)));
+  XLB_HIP(hipMemcpyAsync(cm->flag, &value, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  XLB_NCCL(g_rccl.AllReduce(cm->flag, cm->flag + 1, 1, ncclInt32, ncclMin, cm->comm, c->stream));
+  XLB_HIP(hipMemcpyAsync(out, cm->flag + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  XLB_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int comm_ranks(const xlbhip_ctx* c) { return (c->comm && c->comm->comm) ? c->comm->n_ranks : 1; }
 
 int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t st, int depth) {
   XLB_REQUIRE(depth == 1 || depth == 2, "halo depth must be 1 or 2");
@@ -198,6 +226,7 @@ int xlbhip_comm_init(xlbhip_ctx* c, int rank, int n_ranks, const void* id_bytes,
 int xlbhip_comm_destroy(xlbhip_ctx* c) {
   if (!c || !c->comm) return 0;
   if (c->comm->comm) g_rccl.CommDestroy(c->comm->comm);
+  if (c->comm->flag) (void)hipFree(c->comm->flag);
   delete c->comm;
   c->comm = nullptr;
   return 0;

@@ -9,4 +9,7 @@ namespace xlb {
 int halo_exchange_on(xlbhip_ctx* c, int lattice, xlbhip_field* f, hipStream_t stream, int depth = 1);
 // ghost planes -1 and nx of a per-cell array (nx + 2 halo planes of ny x nz elements)
 int plane_exchange_on(xlbhip_ctx* c, void* base, size_t elem_bytes, int nx, int ny, int nz, int halo, hipStream_t stream);
+// MIN of `value` over the ranks of the context's communicator (blocking; `*out = value` without one)
+int comm_all_min(xlbhip_ctx* c, int value, int* out);
+int comm_ranks(const xlbhip_ctx* c);
 }  // namespace xlb

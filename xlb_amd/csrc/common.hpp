@@ -71,6 +71,7 @@ struct xlbhip_field {
   size_t alloc_bytes = 0;
   void* base = nullptr;  // hipMalloc pointer
   void* data = nullptr;  // base + guard
+  uint64_t version = 0;  // bumped by every C-ABI call that writes the field (caches keyed on a mask's contents)
   size_t cells() const { return (size_t)nx * ny * nz; }
   size_t cells_with_halo() const { return (size_t)(nx + 2 * halo) * ny * nz; }
 };

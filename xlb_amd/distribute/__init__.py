@@ -7,4 +7,7 @@ from .distribute import (
     all_reduce_sum as all_reduce_sum,
     barrier as barrier,
     all_reduce_max as all_reduce_max,
+    all_reduce_min as all_reduce_min,
+    all_gather as all_gather,
+    shutdown as shutdown,
 )

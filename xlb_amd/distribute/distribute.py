@@ -7,9 +7,9 @@ wrap included).  Here each rank keeps ONE ghost x-plane per side, filled before 
 RCCL ``ncclSend``/``ncclRecv`` on a dedicated HIP stream (csrc/comm.cpp) and overlapped with the
 update of the planes that do not touch a ghost (csrc/api.hip: step_once).
 
-Process-group plumbing only (rendezvous, unique-id broadcast, barriers, gathering results for
-tests) goes through ``torch.distributed`` with the ``gloo`` backend; no tensor data of the hot
-path touches torch.
+Process-group plumbing (rendezvous, unique-id broadcast, barriers, small reductions, gathering
+results for tests) goes through ``rendezvous.py`` — a star of plain TCP sockets with rank 0 as the
+hub, standard library only.  Nothing in this package imports torch.
 """
 
 import os
@@ -20,7 +20,7 @@ from .. import _lib
 from ..default_config import get_context
 from ..grid.hip_grid import slab_bounds
 
-_state = {"dist": None, "rank": 0, "world": 1}
+_state = {"rdv": None, "rank": 0, "world": 1}
 
 
 def _env_int(name, default):
@@ -29,28 +29,28 @@ def _env_int(name, default):
 
 
 def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl"):
-    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
-    (as set by ``python -m torch.distributed.run``).  Single-process jobs return (0, 1)
-    without importing torch."""
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (as set by
+    ``python -m torch.distributed.run`` or by ``bench.py``'s launcher).  Single-process jobs return (0, 1).
+
+    ``periodic_x=False``: the global x axis ends in walls, so the ring is a chain — rank 0 and rank N-1
+    exchange nothing (a walled cavity never pulls across that face)."""
     rank, world = _env_int("RANK", 0), _env_int("WORLD_SIZE", 1)
     _state["rank"], _state["world"] = rank, world
     if world == 1:
         return 0, 1
-    import torch.distributed as dist
+    if _state["rdv"] is None:
+        from . import rendezvous
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29500")
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    _state["dist"] = dist
+        _state["rdv"] = rendezvous.from_env()
+    rdv = _state["rdv"]
+    _state["periodic_x"] = bool(periodic_x)
     if init_device_comm:
         ctx = get_context()  # device = XLB_HIP_DEVICE or LOCAL_RANK (default_config._pick_device)
         if transport == "rccl":
-            box = [_lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(rank, world, box[0], periodic_x=periodic_x)
+            uid = rdv.broadcast(_lib.comm_unique_id() if rank == 0 else None, src=0)
+            ctx.comm_init(rank, world, uid, periodic_x=periodic_x)
         elif transport == "host":
-            # debugging transport: ghost planes travel through host memory and gloo (HostStagedHalo);
+            # debugging transport: ghost planes travel through host memory and the rendezvous hub (HostStagedHalo);
             # lets several ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected")
             ctx.rank, ctx.n_ranks = rank, world
             ctx.set_option("external_halo", 1)
@@ -59,12 +59,20 @@ def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl")
     return rank, world
 
 
+def shutdown():
+    """Leave the job: close the control-plane sockets (the device communicator dies with the context)."""
+    if _state["rdv"] is not None:
+        _state["rdv"].close()
+    _state.update(rdv=None, rank=0, world=1)
+
+
 class HostStagedHalo:
-    """Ring halo exchange through host memory + gloo, same messages as csrc/comm.cpp (SlabPlan).
+    """Ring halo exchange through host memory + the rendezvous hub, same messages as csrc/comm.cpp (SlabPlan).
     A debugging transport (orders of magnitude slower than RCCL over xGMI); used with the
     ``external_halo`` option: call ``exchange(f)`` before every step."""
 
-    def __init__(self, grid, velocity_set, periodic=True):
+    def __init__(self, grid, velocity_set, periodic=None):
+        periodic = _state.get("periodic_x", True) if periodic is None else periodic
         self.plan = SlabPlan(grid.shape[0], grid.rank, grid.n_ranks, velocity_set._c[0], periodic=periodic, halo=grid.halo)
 
     def exchange(self, f, depth=1):
@@ -78,22 +86,26 @@ class HostStagedHalo:
             self._run(missing_mask, self.plan.mask_messages())
 
     def _run(self, f, messages):
-        import torch
+        from .rendezvous import pack, unpack
 
-        dist = _state["dist"]
-        reqs, recvs = [], []
-        for _, pops, send_plane, ghost_plane, send_peer, recv_peer in messages:
+        rdv = _state["rdv"]
+        # one frame per peer: the planes of all messages to that peer, in message order (both sides walk the same list)
+        out, expect = {}, []
+        for i, (_, pops, send_plane, ghost_plane, send_peer, recv_peer) in enumerate(messages):
             if send_peer is not None:
-                buf = torch.from_numpy(np.stack([f.get_plane(int(l), send_plane) for l in pops]))
-                reqs.append(dist.isend(buf, dst=send_peer))
+                out.setdefault(send_peer, []).append((i, np.stack([f.get_plane(int(l), send_plane) for l in pops])))
             if recv_peer is not None:
-                rbuf = torch.from_numpy(np.empty((len(pops),) + tuple(f._s3[1:]), dtype=f.plane_dtype))
-                reqs.append(dist.irecv(rbuf, src=recv_peer))
-                recvs.append((pops, ghost_plane, rbuf))
-        for r in reqs:
-            r.wait()
-        for pops, ghost_plane, rbuf in recvs:
-            arr = rbuf.numpy()
+                expect.append((recv_peer, pops, ghost_plane))
+        frames = {}
+        for peer, items in out.items():
+            frames[peer] = pack(np.concatenate([a.reshape(-1) for _, a in items]))
+        got = {src: unpack(b) for src, b in rdv.route(frames).items()}
+        cursor = {src: 0 for src in got}
+        plane = int(np.prod(f._s3[1:]))
+        for src, pops, ghost_plane in expect:
+            n = len(pops) * plane
+            arr = got[src][cursor[src] : cursor[src] + n].reshape((len(pops),) + tuple(f._s3[1:]))
+            cursor[src] += n
             for i, l in enumerate(pops):
                 f.set_plane(int(l), ghost_plane, arr[i])
 
@@ -107,40 +119,34 @@ def world_size():
 
 
 def barrier():
-    if _state["dist"] is not None:
-        _state["dist"].barrier()
+    if _state["rdv"] is not None:
+        _state["rdv"].barrier()
 
 
 def all_reduce_max(value):
-    if _state["dist"] is None:
-        return float(value)
-    import torch
+    return float(value) if _state["rdv"] is None else _state["rdv"].all_reduce(value, "max")
 
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    _state["dist"].all_reduce(t, op=_state["dist"].ReduceOp.MAX)
-    return float(t.item())
+
+def all_reduce_min(value):
+    return float(value) if _state["rdv"] is None else _state["rdv"].all_reduce(value, "min")
 
 
 def all_reduce_sum(value):
-    if _state["dist"] is None:
-        return float(value)
-    import torch
+    return float(value) if _state["rdv"] is None else _state["rdv"].all_reduce(value, "sum")
 
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    _state["dist"].all_reduce(t, op=_state["dist"].ReduceOp.SUM)
-    return float(t.item())
+
+def all_gather(obj):
+    """Every rank's object (JSON-able value, bytes or NumPy array) in rank order."""
+    return [obj] if _state["rdv"] is None else _state["rdv"].all_gather(obj)
 
 
 def gather_field(field):
     """All ranks' slabs concatenated along x -> the global (cardinality, nx, ny, nz) array
     (on every rank).  Test / post-processing helper, not on the hot path."""
     local = field.numpy()
-    dist = _state["dist"]
-    if dist is None:
+    if _state["rdv"] is None:
         return local
-    parts = [None] * _state["world"]
-    dist.all_gather_object(parts, local)
-    return np.concatenate(parts, axis=1)
+    return np.concatenate(_state["rdv"].all_gather(local), axis=1)
 
 
 def distribute(operator, grid, velocity_set, num_results=1, ops="permute"):

@@ -141,12 +141,15 @@ class IncompressibleNavierStokesStepper(Stepper):
     def _run_host_staged(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep):
         """The native run loop with the ghost planes moved by the host (``init_process_group(transport="host")``):
         same kernels and the same pairing of steps as ``xlbhip_run``, the debugging transport in between."""
-        from ...distribute import HostStagedHalo
+        from ...distribute import HostStagedHalo, all_reduce_min
 
         native = self._native_stepper()
         halo = HostStagedHalo(self.grid, self.velocity_set)
         cur, oth, i = f_0, f_1, 0
         fuse = f_0.halo >= 2 and n_steps >= 2 and native.step2_eligible(cur, oth, bc_mask, missing_mask)
+        # the message plan differs between pairs and single steps: the decision must be the same on every rank
+        # (uneven slabs may sit on either side of the two-step kernel's chip-filling rule)
+        fuse = bool(all_reduce_min(1.0 if fuse else 0.0))
         if fuse and bc_mask is not None and self.boundary_conditions:
             halo.exchange_masks(bc_mask, missing_mask)
         while i < n_steps:
