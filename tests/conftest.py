@@ -34,3 +34,15 @@ def _fresh_bc_registry():
 
     boundary_condition_registry.__init__()
     yield
+
+
+@pytest.fixture
+def exact_math():
+    """Bit-exact builds only: fp64 KBC otherwise runs the tolerance-graded fast collision (cell.hpp: kbc_fast), which
+    differs from the oracle by rounding.  Restores the default afterwards (the device context is process-global)."""
+    from xlb_amd.default_config import get_context
+
+    ctx = get_context()
+    ctx.set_option("exact_math", 1)
+    yield ctx
+    ctx.set_option("exact_math", 0)

@@ -92,8 +92,9 @@ def test_config3_twin_d3q19_cavity_vs_golden(walls_cls, tag):
 
 
 @pytest.mark.parametrize("policy", ["FP64FP32", "FP32FP32", "FP64FP64"])
-def test_config5_twin_d3q27_kbc_vs_golden(policy):
-    """BASELINE config 5 twin: D3Q27 KBC, mixed precision (12^3 golden)."""
+def test_config5_twin_d3q27_kbc_vs_golden(policy, exact_math):
+    """BASELINE config 5 twin: D3Q27 KBC, mixed precision (12^3 golden); bit-exact builds (the default fast fp64
+    collision is covered by tests/test_gpu_fastmath.py)."""
     g = golden("d3q27_kbc_12")
     vs, pp = init_hip("D3Q27", policy)
     lat = orc.Lattice("D3Q27")
@@ -137,7 +138,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("lattice,shape,policy,collision,omega,steps", CASES)
-def test_periodic_step_vs_oracle(lattice, shape, policy, collision, omega, steps):
+def test_periodic_step_vs_oracle(lattice, shape, policy, collision, omega, steps, exact_math):
     vs, pp = init_hip(lattice, policy)
     lat = orc.Lattice(lattice)
     grid = grid_factory(shape)

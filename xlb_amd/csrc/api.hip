@@ -155,6 +155,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
+  c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
   return 0;
@@ -869,7 +870,8 @@ static int launch_any(const xlbhip_stepper* s, const StepLaunch& p) {
   }
   if (s->lattice == XLBHIP_D2Q9) return s->collision == XLBHIP_BGK ? launch_step_d2q9_bgk(p) : launch_step_d2q9_kbc(p);
   if (s->lattice == XLBHIP_D3Q19) return launch_step_d3q19_bgk(p);
-  return s->collision == XLBHIP_BGK ? launch_step_d3q27_bgk(p) : launch_step_d3q27_kbc(p);
+  if (s->collision == XLBHIP_BGK) return launch_step_d3q27_bgk(p);
+  return (p.fast_math && p.compute_dtype == XLBHIP_F64) ? launch_step_d3q27_kbc_fast64(p) : launch_step_d3q27_kbc(p);
 }
 
 static int check_step_fields(const xlbhip_stepper* s, const xlbhip_field* a, const xlbhip_field* b, const xlbhip_field* bcm,
@@ -931,6 +933,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.block_threads = (int)opt(c, "block_threads", 256);
   p.block_tz = (int)opt(c, "block_tz", 0);
   p.xcd_swizzle = (int)opt(c, "xcd_swizzle", 0);
+  p.fast_math = opt(c, "exact_math", 0) ? 0 : 1;
   p.stream = c->stream;
   p.x_begin = 0;
   p.x_count = src->nx;

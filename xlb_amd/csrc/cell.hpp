@@ -273,6 +273,140 @@ __device__ __forceinline__ void kbc_fused(T (&f)[L::Q], T rho, const T (&u_in)[3
   });
 }
 
+// ---- KBC, tolerance-graded fast form (COLL_FAST) -------------------------------------------------------------
+// Same algorithm as kbc_fused (kbc.py:58-94), evaluated for speed instead of for bit-identity with the oracle: fused
+// multiply-adds, reciprocals by v_rcp + one Newton step instead of IEEE division (the 27 dh / feq divisions of the
+// entropic scalar products expand to ~11 instructions each in fp64), and the algebra of the (l, opp l) pairs:
+//   feq_l, feq_o = rho w (E +- O),  E = 1 - usqr + 4.5 d^2,  O = 3 d,  d = c_l . u          (one E, O per pair)
+//   cc(l, k) = cc(o, k)  =>  Pi_k += cc (fneq_l + fneq_o);   ds_l = ds_o (the shear part is even)
+//   1 / feq_l = feq_o * r,  1 / feq_o = feq_l * r,  r = 1 / (feq_l feq_o)                   (one reciprocal per pair)
+//   f' = f - beta (2 ds + gamma dh) = (1 - beta gamma) f + beta gamma feq + (beta gamma - 2 beta) ds
+// Results differ from the bit-exact build by rounding only (measured: tests/test_gpu_fastmath.py); the north-star
+// tolerance is 1e-6.  Default for fp64 compute (the VALU-bound case, BASELINE configs[4]); `exact_math=1` selects kbc_fused.
+constexpr int COLL_FAST = 8;
+
+template <class T>
+__device__ __forceinline__ T fast_rcp(T x) {
+  if constexpr (sizeof(T) == 8) {
+    T r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, T(1.0)), r, r);  // v_rcp_f64 is a ~single-precision seed: one Newton step -> ~1e-14
+  } else {
+    return __builtin_amdgcn_rcpf(x);  // 1 ulp
+  }
+}
+
+// k-th population l (index order) with l < opp(l)  [declared below for the packed BGK as well]
+template <class L>
+constexpr int pair_first(int k);
+
+template <class L, class T>
+__device__ __forceinline__ void kbc_fast(T (&f)[L::Q], T omega) {
+  constexpr int Q = L::Q, NP = (Q - 1) / 2;
+  // moments (zero_moment.py:17, first_moment.py:17) with one reciprocal
+  T rho = f[0];
+  static_for<Q - 1>([&](auto lc) { rho = rho + f[decltype(lc)::value + 1]; });
+  T u[3] = {T(0), T(0), T(0)};
+  static_for<Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    static_for<3>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if constexpr (L::c(a, l) == 1) u[a] = u[a] + f[l];
+      if constexpr (L::c(a, l) == -1) u[a] = u[a] - f[l];
+    });
+  });
+  const T inv_rho = fast_rcp(rho);
+  u[0] = u[0] * inv_rho;
+  u[1] = u[1] * inv_rho;
+  u[2] = u[2] * inv_rho;
+  T A = fma(T(-1.5), fma(u[0], u[0], fma(u[1], u[1], u[2] * u[2])), T(1.0));  // 1 - usqr
+  // rho * w per weight class |c|_1 = 0..3
+  T rw[4];
+  static_for<4>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    double w = 0.0;
+    for (int l = 0; l < Q; ++l)
+      if (iabs(L::c(0, l)) + iabs(L::c(1, l)) + iabs(L::c(2, l)) == n) w = L::w(l);
+    rw[n] = rho * T(w);
+  });
+  auto dot_of = [&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    T d = T(0);
+    static_for<3>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if constexpr (L::c(a, l) == 1) d = d + u[a];
+      if constexpr (L::c(a, l) == -1) d = d - u[a];
+    });
+    return d;
+  };
+  constexpr auto norm1 = [](int l) { return iabs(L::c(0, l)) + iabs(L::c(1, l)) + iabs(L::c(2, l)); };
+  // pass 1: Pi = sum cc fneq  (rest population: cc = 0)
+  T pi[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  static_for<NP>([&](auto kc) {
+    constexpr int l = pair_first<L>(decltype(kc)::value), o = opp<L>(l);
+    const T d = dot_of(std::integral_constant<int, l>{});
+    const T E = fma(T(4.5) * d, d, A);
+    const T r = rw[norm1(l)];
+    const T s = (f[l] + f[o]) - (r + r) * E;  // fneq_l + fneq_o (the odd parts cancel)
+    static_for<n_pi<L>()>([&](auto pc) {
+      constexpr int k = decltype(pc)::value;
+      constexpr int v = cc<L>(l, k);
+      if constexpr (v == 1) pi[k] = pi[k] + s;
+      if constexpr (v == -1) pi[k] = pi[k] - s;
+    });
+  });
+  T sh[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  if constexpr (L::ID == XLBHIP_D3Q27) {
+    const T nxz = pi[0] - pi[5], nyz = pi[3] - pi[5];
+    sh[0] = (T(2.0) * nxz - nyz) * T(1.0 / 6.0);
+    sh[1] = (T(2.0) * nyz - nxz) * T(1.0 / 6.0);
+    sh[2] = -(nxz + nyz) * T(1.0 / 6.0);
+    sh[3] = pi[1] * T(0.25);
+    sh[4] = pi[2] * T(0.25);
+    sh[5] = pi[4] * T(0.25);
+  } else {
+    sh[0] = (pi[0] - pi[2]) * T(0.25);
+    sh[1] = pi[1] * T(0.25);
+  }
+  const T beta = T(0.5) * omega;
+  const T inv_beta = fast_rcp(beta);
+  // (keeps the optimiser from carrying the 13 dot products / E / O of one pass into the next: registers, see kbc_fused)
+  launder(A); launder(u[0]); launder(u[1]); launder(u[2]);
+  // pass 2: sp1 = sum dh ds / feq, sp2 = sum dh^2 / feq
+  T sp1 = T(0), sp2 = T(0);
+  {
+    const T fe = rw[0] * A;  // rest population: d = 0, ds = 0
+    const T dh = f[0] - fe;
+    sp2 = dh * dh * fast_rcp(fe);
+  }
+  static_for<NP>([&](auto kc) {
+    constexpr int l = pair_first<L>(decltype(kc)::value), o = opp<L>(l);
+    const T d = dot_of(std::integral_constant<int, l>{});
+    const T E = fma(T(4.5) * d, d, A), O = T(3.0) * d;
+    const T r = rw[norm1(l)];
+    const T fel = r * (E + O), feo = r * (E - O);
+    const T ds = kbc_ds<L, T, l>(sh);
+    const T dhl = (f[l] - fel) - ds, dho = (f[o] - feo) - ds;
+    const T rp = fast_rcp(fel * feo);
+    const T tl = dhl * (feo * rp), to = dho * (fel * rp);
+    sp1 = fma(ds, tl + to, sp1);
+    sp2 = fma(tl, dhl, fma(to, dho, sp2));
+  });
+  const T gamma = inv_beta - ((T(2.0) - inv_beta) * sp1) * fast_rcp(T(1e-32) + sp2);
+  const T bg = beta * gamma, one_m = T(1.0) - bg, kds = bg - (beta + beta);
+  launder(A); launder(u[0]); launder(u[1]); launder(u[2]);
+  // pass 3: f' = (1 - bg) f + bg feq + (bg - 2 beta) ds
+  f[0] = fma(one_m, f[0], bg * (rw[0] * A));
+  static_for<NP>([&](auto kc) {
+    constexpr int l = pair_first<L>(decltype(kc)::value), o = opp<L>(l);
+    const T d = dot_of(std::integral_constant<int, l>{});
+    const T E = fma(T(4.5) * d, d, A), O = T(3.0) * d;
+    const T br = bg * rw[norm1(l)];
+    const T c0 = kds * kbc_ds<L, T, l>(sh);
+    f[l] = fma(one_m, f[l], fma(br, E + O, c0));
+    f[o] = fma(one_m, f[o], fma(br, E - O, c0));
+  });
+}
+
 // ---- Zou-He / Regularized boundary cell (bc_zouhe.py:166-304, bc_regularized.py:78-137) -------
 template <class L>
 constexpr bool is_main(int l) {
@@ -509,7 +643,7 @@ __device__ __forceinline__ int prof_find(const uint32_t* keys, int n, uint32_t k
   return lo;
 }
 
-constexpr int COLL_FORCED = 4;
+constexpr int COLL_FORCED = 4;  // (COLL_FAST = 8 is defined with kbc_fast above)
 
 struct CollideExtra {
   double force[3];
@@ -529,6 +663,8 @@ __device__ __forceinline__ void collide(T (&f)[L::Q], T omega, const CollideExtr
       const T fneq = f[l] - feq_dir<L, T, l>(rho, u, usqr);
       f[l] = f[l] - omega * fneq;
     });
+  } else if constexpr (!FORCED && BASE == XLBHIP_KBC && (COLL & COLL_FAST) != 0) {
+    kbc_fast<L, T>(f, omega);  // (computes its own moments with a reciprocal; the ones above are dead code here)
   } else if constexpr (!FORCED && BASE == XLBHIP_KBC && sizeof(T) == 8) {
     // fp64: 4 x q live doubles do not fit the register file at a useful occupancy; re-evaluating feq
     // wins (D3Q27 FP64FP32 384^3: 16 975 vs 15 089 MLUPS).  In fp32 the array form is faster

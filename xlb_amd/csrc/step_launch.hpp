@@ -36,17 +36,19 @@ struct StepLaunch {
   int block_threads;  // 0 = default (256)
   int block_tz;       // threads along z per block, 0 = as many as fit
   int xcd_swizzle;
+  int fast_math;  // 1: tolerance-graded fast collision where one is built (fp64 KBC: cell.hpp kbc_fast); 0: bit-exact builds only
   hipStream_t stream;
 };
 
 // which (T, S, VEC) combinations exist: fp32 compute -> VEC in {1, 2, 4}; fp64 compute -> {1, 2}
 inline int pick_vec(int compute_dtype, int nz, int requested, int collision) {
-  // Measured on MI355X (profiles/r01_sweeps.md): one cell per thread wins for D3Q19 fp32 at 512^3
-  // (44-60 VGPRs -> 8 waves/SIMD; 75.9 % of the HBM peak vs 74.5 % for VEC=2 and 72.9 % for VEC=4),
-  // so "auto" (0) means 1 — except fp64 KBC, which is VALU/register-bound and prefers 2.
+  // Measured on MI355X: one cell per thread wins everywhere — D3Q19 fp32 at 512^3 (profiles/r01/sweeps.md: 44-60 VGPRs ->
+  // 8 waves/SIMD; 75.9 % of the HBM peak vs 74.5 % for VEC=2 and 72.9 % for VEC=4) and fp64 KBC at 384^3
+  // (profiles/r02/d3q27_kbc_384_sweep.txt: 122 VGPRs / 4 waves vs 164 / 3; 0.684 vs 0.618 of peak), so "auto" (0) means 1.
   // Wider variants stay selectable through the "vec" option.
   const int vmax = (compute_dtype == XLBHIP_F32) ? 4 : 2;
-  int v = requested > 0 ? requested : ((collision == XLBHIP_KBC && compute_dtype == XLBHIP_F64) ? 2 : 1);
+  (void)collision;
+  int v = requested > 0 ? requested : 1;
   if (v > vmax) v = vmax;
   if (v == 3) v = 2;
   if (nz % v != 0) v = 1;
@@ -160,7 +162,18 @@ int launch_step_ext(const StepLaunch& p) {
   XLB_FAIL("SmagorinskyLESBGK / forced collisions are built for FP32FP32, FP64FP64 and FP64FP32 only (got compute=%d store=%d)", c, s);
 }
 
+// fp64-compute policies only (the fast KBC variant: cell.hpp kbc_fast)
+template <class L, int COLL>
+int launch_step_f64(const StepLaunch& p) {
+  const int c = p.compute_dtype, s = p.store_dtype;
+  if (c == XLBHIP_F64 && s == XLBHIP_F64) return launch_policy<L, double, double, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F32) return launch_policy<L, double, float, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F16) return launch_policy<L, double, _Float16, COLL>(p);
+  XLB_FAIL("fast fp64 variant asked for compute=%d store=%d", c, s);
+}
+
 // defined one per translation unit (step_<lattice>_<collision>.hip)
+int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 // two steps per pass (step2_kernel.hpp): f(t) in src -> f(t+2) in dst
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
