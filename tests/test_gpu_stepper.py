@@ -272,6 +272,33 @@ def test_two_step_fusion_matches_oracle(shape, walls_cls, steps):
         ctx.set_option("fuse2", 1)
 
 
+@pytest.mark.parametrize("shape", [(5, 8, 64), (4, 16, 128), (7, 8, 64)])
+@pytest.mark.parametrize("steps", [2, 3, 6])
+def test_two_step_fusion_d3q27_periodic(shape, steps):
+    """D3Q27 BGK fp32 through the two-step kernel (periodic boxes: the 54-plane lifetime-packed LDS ring has no room for
+    the boundary-condition form): same bits as the oracle; a stepper with walls must stay on the single-step kernel."""
+    vs, pp = init_hip("D3Q27")
+    lat = orc.Lattice("D3Q27")
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        grid = grid_factory(shape)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[])
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        f_np = orc.perturbed_init(shape, lat, seed=31)
+        f_0.assign(f_np)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.7, steps)
+        o_bm, o_mm = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+        assert np.array_equal(f_0.numpy(), orc.run(f_np, o_bm, o_mm, [], 1.7, lat, steps))
+        grid, bcs, lat, obcs = hip_cavity_3d((4, 8, 64), FullwayBounceBackBC, lattice="D3Q27")
+        st2 = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        g_0, g_1, bm, mm = st2.prepare_fields()
+        assert not st2._native_stepper().step2_eligible(g_0, g_1, bm, mm)
+    finally:
+        ctx.set_option("fuse2", 1)
+
+
 @pytest.mark.parametrize("shape", [(20, 8, 64), (16, 16, 64), (6, 8, 64)])
 @pytest.mark.parametrize("walls_cls", [None, FullwayBounceBackBC, HalfwayBounceBackBC])
 @pytest.mark.parametrize("steps", [2, 5, 8])

@@ -154,6 +154,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
+  c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
@@ -840,7 +841,7 @@ struct xlbhip_stepper {
   uint64_t scan_version = 0;
   int scan_flag = 1;
   uint32_t* tile_order = nullptr;  // two-step kernel: block -> (8 x 64) tile, hull tiles first
-  int order_ty = 0, order_tz = 0;
+  int order_ty = 0, order_tz = 0, order_mode = -1;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
   size_t meta_cells = 0;
   bool forced = false;
@@ -895,6 +896,22 @@ static int check_step_fields(const xlbhip_stepper* s, const xlbhip_field* a, con
   return 0;
 }
 
+// tile of the two-step kernel: (8 x 64); the (16 x 32) form (fuse2_tile = 2) exists in -DXLB_TUNE_VARIANTS builds only
+static int fuse2_tile_ty(const xlbhip_ctx* c) {
+#ifdef XLB_TUNE_VARIANTS
+  if (opt(c, "fuse2_tile", 0) == 2) return 16;
+#endif
+  (void)c;
+  return 8;
+}
+static int fuse2_tile_tz(const xlbhip_ctx* c) {
+#ifdef XLB_TUNE_VARIANTS
+  if (opt(c, "fuse2_tile", 0) == 2) return 32;
+#endif
+  (void)c;
+  return 64;
+}
+
 static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                               double omega) {
   xlbhip_ctx* c = s->ctx;
@@ -906,6 +923,8 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.meta = nullptr;
   p.tile_order = nullptr;
   p.x_segments = 1;
+  p.tile_ty = fuse2_tile_ty(c);
+  p.tile_tz = fuse2_tile_tz(c);
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -957,7 +976,7 @@ static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
     while (n > 1 && p.x_count / n < 8) n /= 2;
     return n;
   }
-  const long tiles = (long)(p.ny / 8) * (p.nz / 64), cus = fill_cus(s->ctx);
+  const long tiles = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz), cus = fill_cus(s->ctx);
   int best = 1;
   long best_cost = -1;
   for (int n = 1; n <= 8; n *= 2) {
@@ -990,6 +1009,9 @@ static int outflow_aux(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field*
 }
 
 static int launch_any(const xlbhip_stepper* s, const StepLaunch& p);
+static int launch_step2(const xlbhip_stepper* s, const StepLaunch& p) {
+  return s->lattice == XLBHIP_D3Q27 ? launch_step2_d3q27_bgk(p) : launch_step2_d3q19_bgk(p);
+}
 
 // Pair of steps for a stepper whose Zou-He / Regularized / outflow cells all sit in the planes x = 0 and x = nx - 1
 // (inlet / outlet faces): the two-step kernel updates the planes 2 .. nx-3, whose two-step cone never evaluates such a
@@ -1029,12 +1051,12 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   // hull tiles first only pays when they are much more expensive than fluid tiles (halfway walls: redirected
   // loads); with fullway / equilibrium boundaries the XCD-compact order is faster (fuse2_lpt: 0 never, 1 auto, 2 always)
   const int64_t lpt = opt(s->ctx, "fuse2_lpt", 1);
-  p.tile_order = (p.has_bc && (lpt == 2 || (lpt == 1 && s->needs_missing))) ? s->tile_order : nullptr;
+  p.tile_order = (p.has_bc && (lpt >= 2 || (lpt == 1 && s->needs_missing))) ? s->tile_order : nullptr;
   p.x_segments = fuse2_segments(s, p);
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
   if (s->edge_ext_ok) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
-  if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2_d3q19_bgk(p);
+  if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2(s, p);
   // slab protocol for a PAIR of steps: the two ghost planes per side of src are refilled on the comm stream
   // (comm.cpp, depth 2) while the planes whose two-step cone stays inside the slab are updated; the two edge
   // plane pairs follow (each warms its own 3-plane window up from the fresh ghosts).
@@ -1045,19 +1067,19 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   XLB_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
   if (!overlap) {
     XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_step2_d3q19_bgk(p);
+    return launch_step2(s, p);
   }
   p.x_begin = 2;
   p.x_count = src->nx - 4;
   p.x_segments = fuse2_segments(s, p);
-  if (int rc = launch_step2_d3q19_bgk(p)) return rc;
+  if (int rc = launch_step2(s, p)) return rc;
   XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
   p.x_segments = 1;
   p.x_count = 2;
   p.x_begin = 0;
-  if (int rc = launch_step2_d3q19_bgk(p)) return rc;
+  if (int rc = launch_step2(s, p)) return rc;
   p.x_begin = src->nx - 2;
-  return launch_step2_d3q19_bgk(p);
+  return launch_step2(s, p);
 }
 
 static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
@@ -1101,13 +1123,13 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   if (mode == 1) {
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
-    const long items = (long)(p.ny / 8) * (p.nz / 64) * fuse2_segments(s, p), cus = fill_cus(s->ctx);
+    const long items = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz) * fuse2_segments(s, p), cus = fill_cus(s->ctx);
     const long rounds = (items + cus - 1) / cus;
     if (items * 100 < rounds * cus * 85) return false;
     // halfway walls make the hull tiles ~1.5x as expensive as fluid tiles; when most tiles are hull tiles two single
     // steps are faster (256^3, 53 % hull tiles: fused 41.7 vs 38.2 GLUPS; thinner domains lose)
     if (s->needs_missing) {
-      const long tys = p.ny / 8, tzs = p.nz / 64;
+      const long tys = p.ny / p.tile_ty, tzs = p.nz / p.tile_tz;
       const long hull = tys * tzs - (tys > 2 ? tys - 2 : 0) * (tzs > 2 ? tzs - 2 : 0);
       if (hull * 100 > tys * tzs * 60) return false;
     }
@@ -1127,22 +1149,54 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
     s->meta_cells = cells;
   }
-  const int tys = bcm->ny / 8, tzs = bcm->nz / 64;
-  if (s->order_ty != tys || s->order_tz != tzs) {
-    // hull tiles first (the expensive ones when there are walls), then the interior in XCD-friendly order
-    std::vector<uint32_t> order;
-    order.reserve((size_t)tys * tzs);
-    for (int ty = 0; ty < tys; ++ty)
-      for (int tz = 0; tz < tzs; ++tz)
-        if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) order.push_back((uint32_t)(ty * tzs + tz));
-    std::vector<uint32_t> inner;
+  const int tys = bcm->ny / fuse2_tile_ty(c), tzs = bcm->nz / fuse2_tile_tz(c);
+  const int order_mode = opt(c, "fuse2_lpt", 1) == 3 ? 3 : 0;
+  if (s->order_ty != tys || s->order_tz != tzs || s->order_mode != order_mode) {
+    s->order_mode = order_mode;
+    // hull tiles first (the expensive ones when there are walls), then the interior; both lists are dealt so that every
+    // XCD (block i runs on XCD i % 8) works on a CONTIGUOUS run of tiles — neighbours share their halo rows / lines
+    // through that XCD's L2 (fuse2_lpt = 3: the hull in row-major order as in round 1, for A/B)
+    std::vector<uint32_t> hull, inner;
+    if (opt(c, "fuse2_lpt", 1) == 3) {
+      for (int ty = 0; ty < tys; ++ty)
+        for (int tz = 0; tz < tzs; ++tz)
+          if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) hull.push_back((uint32_t)(ty * tzs + tz));
+    } else {
+      // walk around the perimeter: consecutive entries are adjacent tiles
+      for (int tz = 0; tz < tzs; ++tz) hull.push_back((uint32_t)tz);
+      for (int ty = 1; ty < tys - 1; ++ty)
+        if (tzs > 1) hull.push_back((uint32_t)(ty * tzs + tzs - 1));
+      if (tys > 1)
+        for (int tz = tzs - 1; tz >= 0; --tz) hull.push_back((uint32_t)((tys - 1) * tzs + tz));
+      for (int ty = tys - 2; ty >= 1; --ty) hull.push_back((uint32_t)(ty * tzs));
+    }
     for (int ty = 1; ty < tys - 1; ++ty)
       for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
-    const size_t n_in = inner.size(), per = (n_in + 7) / 8;
-    for (size_t i = 0; i < per * 8; ++i) {  // block i -> XCD i % 8 -> its contiguous chunk of the interior list
-      const size_t j = (i % 8) * per + i / 8;
-      if (j < n_in) order.push_back(inner[j]);
-    }
+    std::vector<uint32_t> order;
+    order.reserve((size_t)tys * tzs);
+    auto deal = [&](const std::vector<uint32_t>& list, bool chunked) {
+      const size_t n = list.size(), per = (n + 7) / 8;
+      if (!chunked) {
+        order.insert(order.end(), list.begin(), list.end());
+        return;
+      }
+      // chunk k = list[k * per ...]; the slot being filled decides the XCD (slot % 8) and takes the next tile of that
+      // XCD's chunk (of the fullest chunk once its own is used up)
+      size_t cur[8], end[8];
+      for (size_t k = 0; k < 8; ++k) {
+        cur[k] = std::min(n, k * per);
+        end[k] = std::min(n, (k + 1) * per);
+      }
+      for (size_t done = 0; done < n; ++done) {
+        size_t k = order.size() % 8;
+        if (cur[k] == end[k])
+          for (size_t m = 0; m < 8; ++m)
+            if (end[m] - cur[m] > end[k] - cur[k]) k = m;
+        order.push_back(list[cur[k]++]);
+      }
+    };
+    deal(hull, opt(c, "fuse2_lpt", 1) != 3);
+    deal(inner, true);
     if (s->tile_order) XLB_HIP(hipFree(s->tile_order));
     s->tile_order = nullptr;
     XLB_HIP(hipMalloc(&s->tile_order, order.size() * sizeof(uint32_t)));

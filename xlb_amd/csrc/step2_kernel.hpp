@@ -19,18 +19,61 @@
 #pragma once
 #include "step_kernel.hpp"
 
+#ifndef XLB_STEP2_ALIGN
+#define XLB_STEP2_ALIGN 256
+#endif
+
 namespace xlb {
 
+// LDS ring of f(t+1), packed by population LIFETIME.  Plane p of f(t+1) is produced by phase A of iteration p - 2 and
+// consumed by phase B of plane p + c_x (the pull f_l(x) <- f_l(x - c_x)): its c_x = -1 populations one iteration later,
+// the c_x = 0 ones two, the c_x = +1 ones three iterations later.  So population l needs life(l) = 1 / 2 / 3 plane
+// buffers instead of 3: D3Q19 5 + 18 + 15 = 38 population-planes instead of 57, D3Q27 54 instead of 81 (which is what
+// makes a D3Q27 instantiation fit the 160 KiB at all).  Plane q (counted from x_lo - 1) of population l lives in buffer
+// q % life(l).  With boundary conditions a halfway wall in phase B of plane x also reads the OWN cell's opposite
+// populations of plane x — every group must still be there then, so the c_x = -1 group gets a second buffer (43 / 63).
+// (Serving those reads by letting phase A pre-write the value into the entry phase B pulls from was built and dropped:
+// two adjacent solid cells need two different values in the same entry.)
+// PACKED = false keeps three whole planes ([plane % 3][population][cell], round 1's layout): measured 5-7 % FASTER for
+// D3Q19 on the periodic box and 1 % on the cavity (same box, profiles/r02/sweeps.md) — with one block per CU either way
+// the bytes saved buy nothing at 512^3 (a 12 x 64 tile does not divide 512 and needs <= 128 VGPRs, 16 x 32 is slower),
+// and the packed form costs ~20 more address instructions per plane in a kernel bound by VALU issue.  D3Q27 needs it.
+template <class L, int HASBC, bool PACKED>
+struct S2Ring {
+  static constexpr int life(int l) { return !PACKED ? 3 : (L::c(0, l) == -1 ? (HASBC != 0 ? 2 : 1) : (L::c(0, l) == 0 ? 2 : 3)); }
+  // layout: group-major — [c_x = -1 group: life x n_m planes][c_x = 0: 2 x n_z][c_x = +1: 3 x n_p], a plane buffer of a
+  // group is contiguous, so that one VGPR base per group + an immediate offset per population addresses everything
+  static constexpr int group(int l) { return L::c(0, l) + 1; }  // 0: c_x = -1, 1: c_x = 0, 2: c_x = +1
+  static constexpr int gcount(int g) {
+    int n = 0;
+    for (int m = 0; m < L::Q; ++m) n += group(m) == g ? 1 : 0;
+    return n;
+  }
+  static constexpr int gidx(int l) {  // position of l inside its group
+    int n = 0;
+    for (int m = 0; m < l; ++m) n += group(m) == group(l) ? 1 : 0;
+    return n;
+  }
+  static constexpr int glife(int g) { return !PACKED ? 3 : (g == 0 ? (HASBC != 0 ? 2 : 1) : (g == 1 ? 2 : 3)); }
+  static constexpr int gbase(int g) {  // first population-plane of group g
+    int b = 0;
+    for (int k = 0; k < g; ++k) b += glife(k) * gcount(k);
+    return b;
+  }
+  static constexpr int PLANES = gbase(3);  // population-planes held in LDS
+};
+
 // tile geometry of one instantiation
-template <int TY, int TZ>
+template <class L, int HASBC, int TY, int TZ, bool PACKED>
 struct S2Geom {
   static constexpr int EY = TY + 2, EZ = TZ + 2;
   static constexpr int NE = EY * EZ;                     // cells of f(t+1) per plane slot (grown tile)
   static constexpr int NB = TY * TZ;                     // output cells per plane
   static constexpr int THREADS = (NE + 63) / 64 * 64;    // whole waves covering the grown tile
-  // blocks per CU allowed by LDS (3 x 19 x NE x 4 B of 160 KiB) -> waves per SIMD the register allocation must admit
-  static constexpr int BLOCKS_PER_CU = (160 * 1024) / (3 * 19 * NE * 4) > 2 ? 2 : (160 * 1024) / (3 * 19 * NE * 4);
-  static constexpr int WAVES_PER_SIMD = (BLOCKS_PER_CU * THREADS / 64 + 3) / 4;
+  static constexpr int LDS_BYTES = S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + (HASBC != 0 ? 3 * NE * 4 + 1024 : 8);  // ring + meta words + BC constants
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
+  // one block per CU (LDS) -> waves per SIMD the register allocation must admit
+  static constexpr int WAVES_PER_SIMD = (THREADS / 64 + 3) / 4;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every
@@ -73,15 +116,27 @@ __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id
 // plane 0, so that plane indices -2 .. nx + 1 address the ghosts directly and x never wraps.  (A compile-time
 // switch: the kernel sits at the SGPR limit — 19 uniform row bases per plane — and a run-time halo offset pushed
 // it into scratch spills, which also broke the hand-counted vmcnt of the fix-up loads.)
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB>
-__global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
-  using G = S2Geom<TY, TZ>;
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED>
+__global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
+  using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
+  using R = S2Ring<L, HASBC, PACKED>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
   static_assert(sizeof(T) == 4, "k_step2 keeps f(t+1) as fp32 in LDS");
-  __shared__ T lds[3 * Q * NE];                          // [slot][l][cell]  (8x64 tile: 150 480 B -> one block per CU)
+  __shared__ T lds[R::PLANES * NE];                      // [population-plane of the ring][cell]  (D3Q19, 8x64 tile: 100 320 B)
   __shared__ unsigned ldsmeta[HASBC ? 3 * NE : 1];       // [slot][cell] id | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];     // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
+  // first cell of the buffer that holds population l of plane q (q counted from x_lo - 1; uniform)
+  auto ring = [&](auto lc, int q) -> int {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (!PACKED) {
+      return (q % 3) * (Q * NE) + l * NE;
+    } else {
+      constexpr int g = R::group(l), life = R::glife(g);
+      const int buf = life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3);
+      return (R::gbase(g) + buf * R::gcount(g)) * NE + R::gidx(l) * NE;
+    }
+  };
 
   // tile of this block: from the launch's order table when there is one (hull tiles first — with boundary
   // conditions they are the expensive ones, and a CU that starts with one should get a cheap one next), else
@@ -261,7 +316,8 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
-  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int slot, bool steady) {
+  // q: plane counted from x_lo - 1 (ring buffers q & 1 and q % 3; meta slot q % 3)
+  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int q, bool steady) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
@@ -296,23 +352,34 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     }
     finish(f, fullway);
     if (act_a) {
-      T* dst = lds + slot * (Q * NE) + t;
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        dst[l * NE] = to_compute<T, S>(to_store<S, T>(f[l]));  // f(t+1) passes through the store precision
-      });
-      if constexpr (HASBC != 0) ldsmeta[slot * NE + t] = w;
+      if constexpr (!PACKED) {
+        T* dst = lds + (q % 3) * (Q * NE) + t;
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          dst[l * NE] = to_compute<T, S>(to_store<S, T>(f[l]));  // f(t+1) passes through the store precision
+        });
+      } else {
+        // one pointer per group buffer + a compile-time offset per population (pointer form: see phase B)
+        T* gb[3];
+        static_for<3>([&](auto gc) {
+          constexpr int g = decltype(gc)::value, life = R::glife(g);
+          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3)) * R::gcount(g)) * NE + t;
+        });
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          gb[R::group(l)][R::gidx(l) * NE] = to_compute<T, S>(to_store<S, T>(f[l]));
+        });
+      }
+      if constexpr (HASBC != 0) ldsmeta[(q % 3) * NE + t] = w;
     }
   };
 
-  // phase B: f(t+2) on plane x from the LDS slots of planes x-1, x, x+1 -> global (19 unconditional stores)
-  auto phase_b_compute = [&](T(&f)[Q], int slot_m, int slot_0, int slot_p) {
-    const T* base[3];  // index c_x + 1 -> plane x - c_x
-    base[0] = lds + slot_p * (Q * NE);
-    base[1] = lds + slot_0 * (Q * NE);
-    base[2] = lds + slot_m * (Q * NE);
+  // phase B: f(t+2) on plane x from the ring (planes x-1, x, x+1) -> global (Q unconditional stores)
+  // d = x - x_lo: plane x is plane q = d + 1 of the ring
+  auto phase_b_compute = [&](T(&f)[Q], int d) {
+    const int q0 = d + 1;  // plane x; the pull of population l comes from plane q0 - c_x(l)
     unsigned w = 0;
-    if constexpr (HASBC != 0) w = ldsmeta[slot_0 * NE + ctr_b];
+    if constexpr (HASBC != 0) w = ldsmeta[(q0 % 3) * NE + ctr_b];
     unsigned mall = 0, mm = 0;
     if constexpr (HASBC != 0) {
       const unsigned kind = meta_kind(w);
@@ -320,11 +387,31 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       mall = wave_or(mm);  // uniform; all lanes of the wave are active here (NB is a whole number of waves)
     }
     if (mall == 0u) {  // fluid wave (or only fullway / equilibrium lanes): one scalar branch, then straight-line reads
-      static_for<Q>([&](auto lc) {
-        constexpr int l = decltype(lc)::value;
-        constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
-      });
+      if constexpr (!PACKED) {
+        const T* base[3];  // index c_x + 1 -> plane x - c_x
+        base[0] = lds + ((q0 + 1) % 3) * (Q * NE);
+        base[1] = lds + (q0 % 3) * (Q * NE);
+        base[2] = lds + ((q0 - 1) % 3) * (Q * NE);
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+          f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
+        });
+      } else {
+        // (pointer + immediate form; indexing one array with run-time buffer offsets — lds[ring(l, q) + ...] — compiles to
+        // the same instruction mix but measured 9 % slower on the periodic box: profiles/r02/step2_sweeps.txt)
+        const T* gb[3];  // group g = c_x + 1 comes from plane q0 - c_x
+        static_for<3>([&](auto gc) {
+          constexpr int g = decltype(gc)::value, life = R::glife(g);
+          const int qs = q0 - (g - 1);
+          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (qs & 1) : qs % 3)) * R::gcount(g)) * NE;
+        });
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int cy = L::c(1, l), cz = L::c(2, l);
+          f[l] = gb[R::group(l)][R::gidx(l) * NE + ctr_b - cy * EZ - cz];
+        });
+      }
     } else {
       // boundary wave: a lane whose missing bit l is set reads its own cell's opposite population instead (select on
       // the LDS index, no branch), then the halfway-wall terms are applied to exactly those populations
@@ -332,8 +419,8 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-        const int idx_pull = (cx + 1 == 0 ? slot_p : (cx + 1 == 1 ? slot_0 : slot_m)) * (Q * NE) + l * NE + ctr_b - cy * EZ - cz;
-        const int idx_own = slot_0 * (Q * NE) + opp<L>(l) * NE + ctr_b;
+        const int idx_pull = ring(lc, q0 - cx) + ctr_b - cy * EZ - cz;
+        const int idx_own = ring(std::integral_constant<int, opp<L>(l)>{}, q0) + ctr_b;
         got[l] = lds[((mm >> l) & 1u) ? idx_own : idx_pull];
         f[l] = got[l];
       });
@@ -349,10 +436,10 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
   // the end of the buffer) makes hipcc's vmcnt model exact — with the stores inside `if (act_b)` it waits for the
   // prefetched pulls with vmcnt(19)...vmcnt(1), i.e. drains the wave's own stores every plane — but ran 9 % SLOWER
   // without boundary conditions and the same with them: the kernel is bound by VALU issue, not by these waits.
-  auto phase_b = [&](int x, int slot_m, int slot_0, int slot_p) {
+  auto phase_b = [&](int x, int d) {
     if (!act_b) return;  // whole waves (NB % 64 == 0)
     T f[Q];
-    phase_b_compute(f, slot_m, slot_0, slot_p);
+    phase_b_compute(f, d);
     static_for<Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
@@ -361,16 +448,15 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     });
   };
 
-  // Plane p lives in slot (p + 1) % 3 (p = -1 is the periodic image nx - 1).
+  // Plane x_lo + p is plane q = p + 1 of the ring (p = -1: the periodic image / ghost plane below the segment).
   S raw[Q], fix[Q];
   unsigned w_raw = 0, mall_raw = 0;  // meta word / wave union of the plane held in raw
-  // prologue: planes -1, 0, 1 straight into the window (synchronous), then the pulls of plane 2 go in flight
-  // (slots are keyed on the offset from x_lo: plane x_lo + d lives in slot (d + 1) % 3)
+  // prologue: planes -1, 0, 1 straight into the ring (synchronous), then the pulls of plane 2 go in flight.
   for (int p = -1; p <= 1; ++p) {
     if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + p), cell_a);
     issue_a(wrapx(x_lo + p), raw, fix, w_raw, mall_raw);
     if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
-    finish_a(raw, fix, w_raw, mall_raw, (p + 1) % 3, false);
+    finish_a(raw, fix, w_raw, mall_raw, p + 1, false);
   }
   if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + 2), cell_a);
   issue_a(wrapx(x_lo + 2), raw, fix, w_raw, mall_raw);
@@ -381,9 +467,9 @@ __global__ void __launch_bounds__((S2Geom<TY, TZ>::THREADS), (S2Geom<TY, TZ>::WA
     const int d = x - x_lo;
     unsigned wa = 0;
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
-    phase_b(x, d % 3, (d + 1) % 3, (d + 2) % 3);
-    lds_barrier();  // every reader of the slot about to be overwritten (plane x - 1) is done
-    finish_a(raw, fix, w_raw, mall_raw, d % 3, true);  // plane x + 2 -> slot (d + 3) % 3
+    phase_b(x, d);
+    lds_barrier();  // every reader of the buffers about to be overwritten is done
+    finish_a(raw, fix, w_raw, mall_raw, d + 3, true);  // plane x + 2
     w_raw = wa;
     issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
     lds_barrier();  // plane x + 2 visible

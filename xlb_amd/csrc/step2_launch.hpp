@@ -1,0 +1,49 @@
+// Launcher of the two-steps-per-pass kernel, shared by its per-lattice translation units (step2_*.hip).
+#pragma once
+#include "step2_kernel.hpp"
+#include "step_launch.hpp"
+
+namespace xlb {
+
+#ifndef XLB_STEP2_PACKED_DEFAULT
+#define XLB_STEP2_PACKED_DEFAULT false
+#endif
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED = XLB_STEP2_PACKED_DEFAULT>
+static int launch2(const StepLaunch& p) {
+  StepArgs<float, float> a;
+  // SLAB: pointers advanced to interior plane 0 (the kernel addresses the ghost planes with negative indices)
+  const size_t ghost = (size_t)p.halo * p.ny * p.nz;
+  a.src = static_cast<const float*>(p.src) + ghost;
+  a.dst = static_cast<float*>(p.dst) + ghost;
+  a.bc = p.bc;
+  a.miss = p.miss;
+  a.meta = p.meta ? p.meta + ghost : nullptr;
+  a.tile_order = p.tile_order;
+  a.x_segments = (p.x_segments > 1 && p.x_count >= 8 * p.x_segments) ? p.x_segments : 1;
+  a.bc_kind = p.tab_kind;
+  a.bc_values = static_cast<const float*>(p.tab_values);
+  a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)
+  a.prof_vals = nullptr;
+  a.n_prof = 0;
+  a.ids_packed = p.ids_packed;
+  a.kinds_packed = p.kinds_packed;
+  a.n_bc = p.n_bc;
+  a.plane_stride = p.plane_stride;
+  a.nx = p.nx;
+  a.ny = p.ny;
+  a.nz = p.nz;
+  a.halo = p.halo;
+  a.x_begin = p.x_begin;
+  a.x_count = p.x_count;
+  a.nzq = p.nz;
+  a.omega = static_cast<float>(p.omega);
+  a.extra.force[0] = a.extra.force[1] = a.extra.force[2] = 0.0;
+  a.extra.smag_cs = p.smag_cs;
+  const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
+  a.xcd_swizzle = (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0;
+  hipLaunchKernelGGL((k_step2<L, float, float, XLBHIP_BGK, HASBC, TY, TZ, SLAB, PACKED>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
+  XLB_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace xlb

@@ -14,6 +14,7 @@ struct StepLaunch {
   const uint32_t* meta;  // two-step kernel only
   const uint32_t* tile_order;  // two-step kernel only
   int x_segments;              // two-step kernel only
+  int tile_ty, tile_tz;        // two-step kernel only: tile of the (y, z) plane a block owns
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
   const uint32_t* prof_keys;  // profile table of Zou-He / Regularized BCs (sorted storage cell indices), or nullptr
@@ -177,6 +178,7 @@ int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 // two steps per pass (step2_kernel.hpp): f(t) in src -> f(t+2) in dst
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
+int launch_step2_d3q27_bgk(const StepLaunch& p);
 int launch_step_d2q9_ext(const StepLaunch& p, int coll);
 int launch_step_d3q19_ext(const StepLaunch& p, int coll);
 int launch_step_d3q27_ext(const StepLaunch& p, int coll);
