@@ -88,3 +88,23 @@ def test_two_step_kernel_does_not_spill(tmp_path):
     assert "scratch_" not in text, "k_step2 spills to scratch"
     sizes = [int(m) for m in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
     assert sizes and all(v == 0 for v in sizes), sizes
+    # The hand-placed `s_waitcnt vmcnt(19)` (inline asm, between ;;#ASMSTART / ;;#ASMEND) retires the redirected own-cell loads of a
+    # boundary wave while leaving the 19 stores of the phase B that ran in between in flight.  That is only correct while
+    # at least 19 vector-memory operations are issued between those loads and the wait: check it on the compiled code —
+    # walking back from every such wait, 19 global stores must come before the previous block of asm fix-up loads.
+    lines = text.splitlines()
+    waits = [i for i, l in enumerate(lines) if l.strip() == "s_waitcnt vmcnt(19)" and lines[i - 1].strip() == ";;#ASMSTART"]
+    assert len(waits) >= 2, "hand-placed vmcnt(19) not found in the boundary-condition variants"
+    for w in waits:
+        stores = 0
+        i = w - 2
+        while i > 0:
+            t = lines[i].strip()
+            if t.startswith("global_store_dword"):
+                stores += 1
+            if t.startswith("global_load_dword") and any(lines[k].strip() == ";;#ASMSTART" for k in range(max(0, i - 3), i)):
+                break  # the asm fix-up loads of the previous issue_a
+            if re.match(r"^_ZN3xlb7k_step2", t):
+                break
+            i -= 1
+        assert stores >= 19, f"only {stores} stores between the fix-up loads and the counted wait at line {w}"

@@ -114,3 +114,59 @@ def test_cavity_512_slab_layout_equals_plain_layout():
         for fld in (f_0, f_1, bc_mask, missing_mask):
             fld.free()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+def test_config5_fullsize_d3q27_kbc_fp64fp32_tiling(exact):
+    """BASELINE configs[4] at full size (D3Q27 KBC, fp64 compute / fp32 store, 384^3): a 12^3-periodic pattern tiled over
+    the domain must stay the tiling of the 12^3 oracle solution — exercises the fp64 kernel's addressing at full size.
+    Bit for bit with exact_math=1; within the north-star tolerance (in fact to rounding) with the default fast collision."""
+    from xlb_amd.default_config import get_context
+
+    n, t, steps, omega = 384, 12, 6, 1.9
+    vs, pp = init_hip("D3Q27", "FP64FP32")
+    ctx = get_context()
+    lat = orc.Lattice("D3Q27")
+    tile = orc.perturbed_init((t, t, t), lat, "FP64FP32", seed=17, amp_rho=0.02, amp_u=0.03)
+    bm, mm = np.zeros((1, t, t, t), np.uint8), np.zeros((lat.q, t, t, t), bool)
+    exp_tile = orc.run(tile, bm, mm, [], omega, lat, steps, "FP64FP32", "KBC")
+    reps = n // t
+    try:
+        ctx.set_option("exact_math", exact)
+        grid = grid_factory((n, n, n))
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[], collision_type="KBC")
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        f_0.assign(np.tile(tile, (1, reps, reps, reps)))
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+        out = f_0.numpy()
+    finally:
+        ctx.set_option("exact_math", 0)
+    assert out.dtype == np.float32
+    # every 12^3 block of the result equals block (0, 0, 0) bit for bit (the kernel treats all cells alike) ...
+    blocks = out.reshape(lat.q, reps, t, reps, t, reps, t)
+    assert np.array_equal(blocks, np.broadcast_to(blocks[:, :1, :, :1, :, :1, :], blocks.shape))
+    # ... and that block is the oracle's solution
+    first = np.ascontiguousarray(blocks[:, 0, :, 0, :, 0, :])
+    if exact:
+        assert np.array_equal(first, exp_tile)
+    else:
+        assert np.abs(first.astype(np.float64) - exp_tile.astype(np.float64)).max() <= 1e-6
+
+
+def test_d3q27_two_step_kernel_fullsize_tiling():
+    """D3Q27 BGK fp32 at 384^3 through the two-step kernel (lifetime-packed LDS ring, 2304 work items): the tiled 12^3
+    oracle solution, bit for bit, for an odd step count (pairs + one single step)."""
+    n, t, steps, omega = 384, 12, 7, 1.6
+    vs, pp = init_hip("D3Q27")
+    lat = orc.Lattice("D3Q27")
+    tile = orc.perturbed_init((t, t, t), lat, seed=19)
+    bm, mm = np.zeros((1, t, t, t), np.uint8), np.zeros((lat.q, t, t, t), bool)
+    exp_tile = orc.run(tile, bm, mm, [], omega, lat, steps)
+    reps = n // t
+    grid = grid_factory((n, n, n))
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    f_0.assign(np.tile(tile, (1, reps, reps, reps)))
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+    assert np.array_equal(f_0.numpy(), np.tile(exp_tile, (1, reps, reps, reps)))

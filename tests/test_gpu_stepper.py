@@ -337,3 +337,35 @@ def test_two_step_fusion_slab_protocol(shape, walls_cls, steps):
     finally:
         ctx.set_option("fuse2", 1)
         ctx.set_option("overlap", 1)
+
+
+@pytest.mark.parametrize("faces", [("front", "back"), ("front",), ("bottom", "top")])
+def test_two_step_y_wall_redirect_regression(faces):
+    """Regression for the memory fault of round 1 (gpurun_out/f.err, fixed by commit 2111f4e): halfway walls on the y
+    faces make EVERY wave of a hull tile issue the redirected own-cell loads of the two-step kernel — inline-asm
+    `global_load_dword v, v_off, s[base]` whose SGPR base may have just been written by a VALU (v_readlane of a spilled
+    SGPR); without the `s_nop 4` in front the load used a garbage address.  A domain whose only boundary is a pair of
+    y (or z) walls, several tiles and x-segments, bit for bit against the oracle."""
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    shape, omega, steps = (40, 32, 128), 1.3, 4
+    grid = grid_factory(shape)
+    box = grid.bounding_box_indices()
+    walls = [sum((box[f][i] for f in faces), []) for i in range(3)]
+    bc = HalfwayBounceBackBC(indices=walls)
+    obcs = [orc.BC(orc.KIND_HALFWAY_BB, bc.id, walls)]
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        ctx.set_option("fuse2_xseg", 4)
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[bc])
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        f_np = orc.perturbed_init(shape, lat, seed=37)
+        f_0.assign(f_np)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+        assert np.array_equal(f_0.numpy(), orc.run(f_np, o_bm, o_mm, obcs, omega, lat, steps))
+    finally:
+        ctx.set_option("fuse2", 1)
+        ctx.set_option("fuse2_xseg", 0)
