@@ -72,7 +72,13 @@ enum {
    * with cs * f_post_stream(neighbour behind the face) + (1 - cs) * f_post_stream(cell) ("auxiliary data", read back by
    * the next step).  values[0..2] = outward face normal (internal 3-component form), values[3] = cs = 1/sqrt(3) and
    * values[4] = 1 - cs, both rounded in the compute dtype by the host side. */
-  XLBHIP_BC_EXTRAPOLATION_OUTFLOW = 9
+  XLBHIP_BC_EXTRAPOLATION_OUTFLOW = 9,
+  /* HybridBC (bc_hybrid.py:254-358; kernel backends only in the reference), 3-D lattices.  values[0..2] = wall velocity
+   * (3-component internal form), values[3] != 0: moving-wall treatment, values[4] != 0: use the wall-distance weights the
+   * mesh masker produced (xlbhip_stepper_set_bc_distances) */
+  XLBHIP_BC_HYBRID_BB_REGULARIZED = 10,  /* interpolated bounce-back + regularisation (bc_hybrid.py:256-290) */
+  XLBHIP_BC_HYBRID_BB_GRADS = 11,        /* interpolated bounce-back + Grad's approximation (:292-326) */
+  XLBHIP_BC_HYBRID_NEQ_REGULARIZED = 12  /* non-equilibrium bounce-back + regularisation (:328-358) */
 };
 
 /* One boundary condition as the stepper sees it.  `values` holds, in COMPUTE
@@ -189,6 +195,27 @@ int xlbhip_mesh_mask_aabb(xlbhip_ctx* ctx, int lattice, int bc_id, int64_t n_tri
 int xlbhip_mesh_mask_ray(xlbhip_ctx* ctx, int lattice, int bc_id, int64_t n_triangles, const float* vertices, xlbhip_field* bc_mask,
                          xlbhip_field* missing_mask);
 
+/* Mesh voxelisation methods (xlb/operator/boundary_masker/mesh_voxelization_method.py:13-55) */
+enum { XLBHIP_MESH_AABB = 1, XLBHIP_MESH_RAY = 2, XLBHIP_MESH_AABB_CLOSE = 3, XLBHIP_MESH_WINDING = 4 };
+
+/* All mesh maskers behind one entry, with the wall distances ("weights") curved-wall BCs interpolate with.  Replaces the
+ * warp_implementation of MeshMaskerAABB (aabb.py:38-100), MeshMaskerRay (ray.py:38-101), MeshMaskerWinding
+ * (winding.py:19-115) and MeshMaskerAABBClose (aabb_close.py:26-365; `close_voxels` = half width of the (2h+1)^3
+ * structuring element of the morphological close) — masker(bc, distances, bc_mask, missing_mask).
+ * `distances`: NULL, or a (q, nx, ny, nz) fp32 field that receives, like the reference's `distances` argument,
+ *   RAY        distances[l]     = t / |c_l|            at a boundary voxel whose link along c_l crosses the surface at t
+ *   WINDING    distances[opp l] = (|c_l| - t) / |c_l|  at the fluid neighbour (+c_l) of a solid voxel
+ *   AABB_CLOSE distances[l]     = (t - |c_l| / 2) / |c_l| within 1.5 |c_l|, 1.0 without a hit, for links ending in a solid voxel
+ * (untouched elsewhere).  The Warp BVH queries are replaced by exhaustive closest-hit / exact winding-number loops over
+ * the triangles: O(voxels near the surface x triangles near the voxel) for the rays, O(bounding-box voxels x triangles)
+ * for the winding number. */
+int xlbhip_mesh_mask(xlbhip_ctx* ctx, int lattice, int method, int bc_id, int64_t n_triangles, const float* vertices, int close_voxels,
+                     xlbhip_field* bc_mask, xlbhip_field* missing_mask, xlbhip_field* distances);
+
+/* out[i][l] = field[l][cells[i]] for n interior linear cell indices ((x * ny + y) * nz + z), element type of the field;
+ * blocking.  How boundary-cell data (e.g. the distances above) reach the host without downloading whole fields. */
+int xlbhip_field_gather(const xlbhip_field* f, int64_t n, const uint32_t* cells, void* out, size_t bytes);
+
 /* ---- the stepper (the hot path) ------------------------------------------ */
 /* replaces: IncompressibleNavierStokesStepper._construct_warp + launch,
  * nse_stepper.py:335-476, with the JAX step order of :237-282. */
@@ -201,6 +228,12 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s);
  * (internal 3-component form) or its density in values[3 i].  Replaces the kernel backends' encoding of these values in
  * f_1 (helper_functions_bc.py:371-499, nse_stepper.py:398-425).  May be called once per BC; tables are merged. */
 int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const uint32_t* storage_cells, const double* values);
+
+/* Wall-distance weights of HybridBC cells: n storage cell indices (as for set_bc_profile) and q floats each, in the
+ * layout of the mesh masker's `distances` (the weight of missing direction l in slot opp l).  The reference keeps them
+ * in f_1 and recovers them every step (bc_hybrid.py:207-214, nse_stepper.py:398-425); here they live in a sorted table
+ * that the boundary lanes of the step kernel search.  Calls accumulate (one per mesh BC). */
+int xlbhip_stepper_set_bc_distances(xlbhip_stepper* s, int64_t n, const uint32_t* storage_cells, const float* weights);
 /* ForcedCollision with the exact-difference scheme (forced_collision.py:44-50, exact_difference_force.py:61-83):
  * force[3] in the internal 3-component form; NULL switches forcing off */
 int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force);

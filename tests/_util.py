@@ -89,3 +89,18 @@ def max_ulp_diff(a, b):
     ia = np.where(ia < 0, -(ia + sign) - 0, ia)  # map sign-magnitude to a monotone integer line
     ib = np.where(ib < 0, -(ib + sign) - 0, ib)
     return int(np.abs(ia - ib).max())
+
+
+def icosphere(center, radius, subdivisions=2):
+    """triangle soup (3 n, 3) of a sphere, counter-clockwise seen from outside, built procedurally (no STL reader here)"""
+    t = (1.0 + 5.0**0.5) / 2.0
+    v = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], float)
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6],
+         [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    tris = v[np.array(f)]
+    for _ in range(subdivisions):
+        a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+        ab, bc, ca = (a + b) / 2, (b + c) / 2, (c + a) / 2
+        tris = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1), np.stack([ab, bc, ca], 1)])
+    tris = tris / np.linalg.norm(tris, axis=2, keepdims=True)
+    return (np.asarray(center) + radius * tris).reshape(-1, 3).astype(np.float32)

@@ -135,6 +135,9 @@ def test_stepper_routes_ray_method():
     a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, 15)
     exp = orc.run(f_np, o_bm, o_mm, [orc.BC(orc.KIND_HALFWAY_BB, b_s.id, None)], 1.3, lat, 15)
     assert np.array_equal(a.numpy(), exp)
-    with pytest.raises(Exception, match="AABB and RAY"):
-        bad = HalfwayBounceBackBC(mesh_vertices=verts, voxelization_method=MeshVoxelizationMethod("WINDING"))
-        IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[bad]).prepare_fields()
+    # the stepper routes every voxelisation method (nse_stepper.py:165-203); WINDING fills the ball
+    b_w = HalfwayBounceBackBC(mesh_vertices=verts, voxelization_method=MeshVoxelizationMethod("WINDING"))
+    _, _, bm_w, _ = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_w]).prepare_fields()
+    assert (bm_w.numpy() == 255).sum() > 20
+    with pytest.raises(AssertionError, match="Unsupported voxelization method"):
+        MeshVoxelizationMethod("OCTREE")

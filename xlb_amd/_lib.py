@@ -21,6 +21,8 @@ BGK, KBC, SMAGORINSKY_LES_BGK = 0, 1, 2
 BC_EQUILIBRIUM, BC_HALFWAY_BB, BC_FULLWAY_BB, BC_DO_NOTHING = 1, 2, 3, 4
 BC_ZOUHE_VELOCITY, BC_ZOUHE_PRESSURE, BC_REGULARIZED_VELOCITY, BC_REGULARIZED_PRESSURE = 5, 6, 7, 8
 BC_EXTRAPOLATION_OUTFLOW = 9
+BC_HYBRID_BB_REGULARIZED, BC_HYBRID_BB_GRADS, BC_HYBRID_NEQ_REGULARIZED = 10, 11, 12
+MESH_AABB, MESH_RAY, MESH_AABB_CLOSE, MESH_WINDING = 1, 2, 3, 4
 UNIQUE_ID_BYTES = 128
 
 NP_OF_DTYPE = {F64: np.float64, F32: np.float32, F16: np.float16, U8: np.uint8, BOOL: np.bool_, MISSING: np.uint8}
@@ -67,6 +69,9 @@ SIGNATURES = {
     "xlbhip_vorticity": [_p, _p, _p, _p, _p],
     "xlbhip_mesh_mask_aabb": [_p, _i, _i, _i64, _p, _p, _p],
     "xlbhip_mesh_mask_ray": [_p, _i, _i, _i64, _p, _p, _p],
+    "xlbhip_mesh_mask": [_p, _i, _i, _i, _i64, _p, _i, _p, _p, _p],
+    "xlbhip_field_gather": [_p, _i64, _p, _p, C.c_size_t],
+    "xlbhip_stepper_set_bc_distances": [_p, _i64, _p, _p],
     "xlbhip_grid_to_point": [_p, _p, _i64, _p, _p],
     "xlbhip_momentum_transfer": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, C.POINTER(C.c_double)],
     "xlbhip_stepper_set_bc_profile": [_p, _i, _i64, _p, _p],
@@ -361,6 +366,13 @@ class Field:
         assert a.shape == tuple(self._s3[1:])
         check(load().xlbhip_field_plane_upload(self.handle, int(population), int(storage_plane), a.ctypes.data, a.nbytes))
 
+    def gather(self, cells):
+        """Rows of the field at interior linear cell indices ((x * ny + y) * nz + z): an (n, cardinality) array."""
+        k = np.ascontiguousarray(cells, dtype=np.uint32)
+        out = np.empty((k.shape[0], self.cardinality), dtype=self.dtype)
+        check(load().xlbhip_field_gather(self.handle, int(k.shape[0]), k.ctypes.data, out.ctypes.data, out.nbytes))
+        return out
+
     def copy_kernel_from(self, other, bytes_per_lane=16):
         check(load().xlbhip_field_copy_kernel(self.handle, other.handle, int(bytes_per_lane)))
         return self
@@ -428,6 +440,13 @@ class Stepper:
         v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, 3)
         assert k.shape[0] == v.shape[0]
         check(load().xlbhip_stepper_set_bc_profile(self._h, int(bc_id), int(k.shape[0]), k.ctypes.data, v.ctypes.data))
+
+    def set_bc_distances(self, storage_cells, weights):
+        """Wall-distance weights of HybridBC cells: storage cell indices (uint32) and (n, q) float32 weights."""
+        k = np.ascontiguousarray(storage_cells, dtype=np.uint32)
+        w = np.ascontiguousarray(weights, dtype=np.float32)
+        assert w.ndim == 2 and k.shape[0] == w.shape[0]
+        check(load().xlbhip_stepper_set_bc_distances(self._h, int(k.shape[0]), k.ctypes.data, w.ctypes.data))
 
     def set_smagorinsky(self, coef):
         check(load().xlbhip_stepper_set_smagorinsky(self._h, float(coef)))

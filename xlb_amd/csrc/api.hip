@@ -600,7 +600,9 @@ int xlbhip_apply_bc_profile(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc
   XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_post), "bc: bad bc_mask field");
   XLB_REQUIRE(same_grid(f_pre, f_post), "bc: grids differ");
   XLB_REQUIRE(bc->id >= 1 && bc->id <= 255, "bc id %d out of range", bc->id);
-  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_EXTRAPOLATION_OUTFLOW, "unknown bc kind %d", bc->kind);
+  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d", bc->kind);
+  XLB_REQUIRE(bc->kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || (lattice_d(lattice) == 3 && bc->values[4] == 0.0),
+              "HybridBC as a stand-alone operator: 3-D lattices, without mesh distances (those live in the stepper: xlbhip_stepper_set_bc_distances)");
   if (bc->kind == XLBHIP_BC_HALFWAY_BB || bc->kind >= XLBHIP_BC_ZOUHE_VELOCITY)
     XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_post), "bc: this boundary condition needs a missing_mask field");
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
@@ -823,6 +825,144 @@ extern "C" int xlbhip_mesh_mask_ray(xlbhip_ctx* c, int lattice, int bc_id, int64
   return rc;
 }
 
+// RAII scratch of the mesh maskers: device buffers released (after the stream drained) on every exit path
+namespace {
+struct DeviceScratch {
+  hipStream_t st;
+  std::vector<void*> ptrs;
+  explicit DeviceScratch(hipStream_t s) : st(s) {}
+  ~DeviceScratch() {
+    (void)hipStreamSynchronize(st);
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <class P>
+  hipError_t alloc(P** out, size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) ptrs.push_back(p);
+    *out = static_cast<P*>(p);
+    return e;
+  }
+};
+}  // namespace
+
+// Mesh voxelisation, all methods (boundary_masker/{aabb,ray,winding,aabb_close}.py), with the wall distances.
+extern "C" int xlbhip_mesh_mask(xlbhip_ctx* c, int lattice, int method, int bc_id, int64_t n_triangles, const float* vertices, int close_voxels,
+                                xlbhip_field* bcm, xlbhip_field* miss, xlbhip_field* dist) {
+  if (method == XLBHIP_MESH_AABB && !dist) return xlbhip_mesh_mask_aabb(c, lattice, bc_id, n_triangles, vertices, bcm, miss);
+  if (method == XLBHIP_MESH_RAY && !dist) return xlbhip_mesh_mask_ray(c, lattice, bc_id, n_triangles, vertices, bcm, miss);
+  XLB_REQUIRE(c && bcm && miss && (n_triangles == 0 || vertices), "mesh masker: null argument");
+  XLB_REQUIRE(method == XLBHIP_MESH_RAY || method == XLBHIP_MESH_WINDING || method == XLBHIP_MESH_AABB_CLOSE,
+              "mesh masker: method %d has no wall distances (RAY, WINDING, AABB_CLOSE do)", method);
+  XLB_REQUIRE(lattice == XLBHIP_D3Q19 || lattice == XLBHIP_D3Q27, "MeshBoundaryMasker is only implemented for 3D velocity sets!");
+  XLB_REQUIRE(bcm->dtype == XLBHIP_U8 && bcm->card == 1 && bcm->halo == 0, "mesh masker: bc_mask must be a (1, nx, ny, nz) uint8 field without ghost planes");
+  XLB_REQUIRE(miss->dtype == XLBHIP_MISSING && miss->card == lattice_q(lattice) && same_grid(miss, bcm) && miss->halo == 0, "mesh masker: bad missing_mask field");
+  XLB_REQUIRE(bc_id >= 1 && bc_id <= 254, "bc id %d out of range 1..254", bc_id);
+  XLB_REQUIRE(!dist || (dist->dtype == XLBHIP_F32 && dist->card == lattice_q(lattice) && same_grid(dist, bcm) && dist->halo == 0),
+              "mesh masker: distances must be a (q, nx, ny, nz) fp32 field on the masks' grid");
+  XLB_REQUIRE(method != XLBHIP_MESH_AABB_CLOSE || (close_voxels >= 1 && close_voxels <= 8), "AABB_CLOSE: close_voxels must be 1..8 (got %d)", close_voxels);
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int64_t i = 0; i < n_triangles * 3; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float p = vertices[3 * i + a];
+      const int ext = a == 0 ? bcm->nx : (a == 1 ? bcm->ny : bcm->nz);
+      XLB_REQUIRE(p >= 0.0f && p < (float)ext, "Mesh extents exceed domain dimensions (%d,%d,%d). The mesh must be fully contained within the domain.",
+                  bcm->nx, bcm->ny, bcm->nz);
+      lo[a] = i == 0 ? p : std::min(lo[a], p);
+      hi[a] = i == 0 ? p : std::max(hi[a], p);
+    }
+  touch(bcm);
+  touch(miss);
+  if (dist) touch(dist);
+  if (n_triangles == 0) return 0;
+  hipStream_t st = c->stream;
+  DeviceScratch scratch(st);
+  const Dims d = dims(bcm);
+  const size_t cells = bcm->cells();
+  const int q = lattice_q(lattice);
+  float* dv = nullptr;
+  XLB_HIP(scratch.alloc(&dv, (size_t)n_triangles * 9 * sizeof(float)));
+  XLB_HIP(hipMemcpyAsync(dv, vertices, (size_t)n_triangles * 9 * sizeof(float), hipMemcpyHostToDevice, st));
+  unsigned* tbuf = nullptr;  // closest ray parameter per (link, voxel), +inf = none
+  if (dist || method == XLBHIP_MESH_WINDING) {
+    XLB_HIP(scratch.alloc(&tbuf, (size_t)q * cells * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_fill<unsigned>, blocks_for((size_t)q * cells), 256, 0, st, tbuf, (size_t)q * cells, T_NONE);
+  }
+  uint8_t* bcp = static_cast<uint8_t*>(bcm->data);
+  uint32_t* mp = static_cast<uint32_t*>(miss->data);
+  const FieldView dview = view(dist);
+  return by_lattice(lattice, [&](auto L) {
+    using LL = decltype(L);
+    if (method == XLBHIP_MESH_RAY) {
+      hipLaunchKernelGGL(k_mesh_ray_dist<LL>, blocks_for((size_t)n_triangles), 256, 0, st, dv, n_triangles, bcp, mp, tbuf, d, bc_id);
+      hipLaunchKernelGGL(k_mesh_weights_ray<LL>, blocks_for(cells), 256, 0, st, tbuf, dview, d);
+    } else if (method == XLBHIP_MESH_WINDING) {
+      uint8_t* solid = nullptr;
+      XLB_HIP(scratch.alloc(&solid, cells));
+      XLB_HIP(hipMemsetAsync(solid, 0, cells, st));
+      int b0[3], nb[3];
+      const int ext[3] = {d.nx, d.ny, d.nz};
+      for (int a = 0; a < 3; ++a) {
+        b0[a] = std::max(0, (int)floorf(lo[a]) - 1);
+        nb[a] = std::min(ext[a] - 1, (int)floorf(hi[a]) + 1) - b0[a] + 1;
+      }
+      hipLaunchKernelGGL(k_mesh_winding, blocks_for((size_t)nb[0] * nb[1] * nb[2]), 256, 0, st, dv, n_triangles, solid, d, b0[0], b0[1], b0[2], nb[0],
+                         nb[1], nb[2]);
+      hipLaunchKernelGGL(k_mesh_winding_rays<LL>, blocks_for((size_t)n_triangles), 256, 0, st, dv, n_triangles, solid, tbuf, d);
+      hipLaunchKernelGGL(k_mesh_winding_tag<LL>, blocks_for(cells), 256, 0, st, solid, tbuf, bcp, mp, dview, d, bc_id);
+    } else {
+      const int h = close_voxels, pad = 2 * h;
+      const int px = d.nx + 2 * pad, py = d.ny + 2 * pad, pz = d.nz + 2 * pad;
+      const size_t pcells = (size_t)px * py * pz;
+      uint8_t *pa = nullptr, *pb = nullptr, *solid = nullptr;
+      XLB_HIP(scratch.alloc(&pa, pcells));
+      XLB_HIP(scratch.alloc(&pb, pcells));
+      XLB_HIP(scratch.alloc(&solid, cells));
+      XLB_HIP(hipMemsetAsync(pa, 0, pcells, st));
+      hipLaunchKernelGGL(k_mesh_solid_padded, blocks_for((size_t)n_triangles), 256, 0, st, dv, n_triangles, pa, px, py, pz, pad);
+      hipLaunchKernelGGL(k_morph, blocks_for(pcells), 256, 0, st, pa, pb, px, py, pz, h, 1);
+      hipLaunchKernelGGL(k_morph, blocks_for(pcells), 256, 0, st, pb, pa, px, py, pz, h, 0);
+      hipLaunchKernelGGL(k_crop, blocks_for(cells), 256, 0, st, pa, solid, d, py, pz, pad);
+      hipLaunchKernelGGL(k_mesh_classify<LL>, blocks_for(cells), 256, 0, st, solid, bcp, mp, d, bc_id);
+      if (dist) {
+        hipLaunchKernelGGL(k_mesh_close_rays<LL>, blocks_for((size_t)n_triangles), 256, 0, st, dv, n_triangles, solid, bcp, tbuf, d, bc_id);
+        hipLaunchKernelGGL(k_mesh_weights_close<LL>, blocks_for(cells), 256, 0, st, solid, bcp, tbuf, dview, d, bc_id);
+      }
+    }
+    if (method != XLBHIP_MESH_AABB_CLOSE)  // (k_mesh_classify resolves the out-of-box directions itself)
+      hipLaunchKernelGGL(k_mesh_resolve<LL>, blocks_for(cells), 256, 0, st, bcp, mp, d, bc_id);
+    XLB_HIP(hipGetLastError());
+    return 0;
+  });
+}
+
+extern "C" int xlbhip_field_gather(const xlbhip_field* f, int64_t n, const uint32_t* cells, void* out, size_t bytes) {
+  XLB_REQUIRE(f && (n == 0 || (cells && out)), "field_gather: null argument");
+  XLB_REQUIRE(f->dtype != XLBHIP_MISSING, "field_gather: not for the bit-packed missing_mask");
+  const size_t es = dtype_size(f->dtype);
+  XLB_REQUIRE(bytes == (size_t)n * f->card * es, "field_gather: output size %zu != %zu", bytes, (size_t)n * f->card * es);
+  if (n == 0) return 0;
+  for (int64_t i = 0; i < n; ++i) XLB_REQUIRE(cells[i] < f->cells(), "field_gather: cell %u outside the field", cells[i]);
+  hipStream_t st = f->ctx->stream;
+  DeviceScratch scratch(st);
+  uint32_t* dc = nullptr;
+  char* dout = nullptr;
+  XLB_HIP(scratch.alloc(&dc, (size_t)n * sizeof(uint32_t)));
+  XLB_HIP(scratch.alloc(&dout, bytes));
+  XLB_HIP(hipMemcpyAsync(dc, cells, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  const size_t ghost = (size_t)f->halo * f->ny * f->nz;
+  switch (es) {
+    case 8: hipLaunchKernelGGL(k_gather<uint64_t>, blocks_for((size_t)n), 256, 0, st, (const uint64_t*)f->data, f->plane_stride, ghost, f->card, dc, n, (uint64_t*)dout); break;
+    case 4: hipLaunchKernelGGL(k_gather<uint32_t>, blocks_for((size_t)n), 256, 0, st, (const uint32_t*)f->data, f->plane_stride, ghost, f->card, dc, n, (uint32_t*)dout); break;
+    case 2: hipLaunchKernelGGL(k_gather<uint16_t>, blocks_for((size_t)n), 256, 0, st, (const uint16_t*)f->data, f->plane_stride, ghost, f->card, dc, n, (uint16_t*)dout); break;
+    default: hipLaunchKernelGGL(k_gather<uint8_t>, blocks_for((size_t)n), 256, 0, st, (const uint8_t*)f->data, f->plane_stride, ghost, f->card, dc, n, (uint8_t*)dout); break;
+  }
+  XLB_HIP(hipGetLastError());
+  XLB_HIP(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st));
+  XLB_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
 // ---- stepper --------------------------------------------------------------------------------
 struct xlbhip_stepper {
   xlbhip_ctx* ctx = nullptr;
@@ -858,6 +998,11 @@ struct xlbhip_stepper {
   uint32_t* prof_keys = nullptr;
   void* prof_vals = nullptr;  // compute dtype [n_prof][3]
   int n_prof = 0;
+  // wall-distance weights of HybridBC cells (mesh maskers): host map (storage cell -> q weights) and its sorted device image
+  std::map<uint32_t, std::array<float, 27>> dist_host;
+  uint32_t* dist_keys = nullptr;
+  float* dist_vals = nullptr;  // [n_dist][q]
+  int n_dist = 0;
 };
 
 namespace xlb {
@@ -933,6 +1078,9 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.prof_keys = s->prof_keys;
   p.prof_vals = s->prof_vals;
   p.n_prof = s->n_prof;
+  p.dist_keys = s->dist_keys;
+  p.dist_vals = s->dist_vals;
+  p.n_dist = s->n_dist;
   p.plane_stride = src->plane_stride;
   p.nx = src->nx;
   p.ny = src->ny;
@@ -1281,7 +1429,8 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   for (int i = 0; i < n_bc; ++i) {
     const xlbhip_bc_desc& b = bcs[i];
     XLB_REQUIRE(b.id >= 1 && b.id <= 255, "bc id %d out of range 1..255", b.id);
-    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_EXTRAPOLATION_OUTFLOW, "unknown bc kind %d", b.kind);
+    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d", b.kind);
+    XLB_REQUIRE(b.kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || lattice_d(lattice) == 3, "This BC is not implemented in 2D!");  // bc_hybrid.py:119-120
     if (b.kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) has_outflow = true;
     if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY || b.kind == XLBHIP_BC_DO_NOTHING) has_edge_kinds = true;
     XLB_REQUIRE(kind[b.id] == 0, "bc id %d used twice", b.id);
@@ -1371,6 +1520,40 @@ int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const
   return 0;
 }
 
+int xlbhip_stepper_set_bc_distances(xlbhip_stepper* s, int64_t n, const uint32_t* storage_cells, const float* weights) {
+  XLB_REQUIRE(s, "stepper is null");
+  XLB_REQUIRE(n == 0 || (storage_cells && weights), "null table");
+  xlbhip_ctx* c = s->ctx;
+  const int q = lattice_q(s->lattice);
+  XLB_HIP(hipSetDevice(c->device));
+  XLB_HIP(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < n; ++i) {
+    std::array<float, 27> w{};
+    for (int l = 0; l < q; ++l) w[(size_t)l] = weights[i * q + l];
+    s->dist_host[storage_cells[i]] = w;
+  }
+  std::vector<uint32_t> keys;
+  std::vector<float> vals;
+  keys.reserve(s->dist_host.size());
+  vals.reserve(s->dist_host.size() * (size_t)q);
+  for (const auto& kv : s->dist_host) {  // std::map iterates in key order
+    keys.push_back(kv.first);
+    vals.insert(vals.end(), kv.second.begin(), kv.second.begin() + q);
+  }
+  if (s->dist_keys) XLB_HIP(hipFree(s->dist_keys));
+  if (s->dist_vals) XLB_HIP(hipFree(s->dist_vals));
+  s->dist_keys = nullptr;
+  s->dist_vals = nullptr;
+  s->n_dist = (int)keys.size();
+  if (s->n_dist > 0) {
+    XLB_HIP(hipMalloc(&s->dist_keys, keys.size() * sizeof(uint32_t)));
+    XLB_HIP(hipMemcpy(s->dist_keys, keys.data(), keys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    XLB_HIP(hipMalloc(&s->dist_vals, vals.size() * sizeof(float)));
+    XLB_HIP(hipMemcpy(s->dist_vals, vals.data(), vals.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
 int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force) {
   XLB_REQUIRE(s, "stepper is null");
   s->forced = force != nullptr;
@@ -1392,6 +1575,8 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   (void)hipFree(s->tab_values);
   if (s->prof_keys) (void)hipFree(s->prof_keys);
   if (s->prof_vals) (void)hipFree(s->prof_vals);
+  if (s->dist_keys) (void)hipFree(s->dist_keys);
+  if (s->dist_vals) (void)hipFree(s->dist_vals);
   if (s->scratch) xlbhip_field_destroy(s->scratch);
   if (s->meta) (void)hipFree(s->meta);
   if (s->tile_order) (void)hipFree(s->tile_order);

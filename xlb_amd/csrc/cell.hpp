@@ -512,6 +512,107 @@ __device__ __forceinline__ void zouhe_cell(T (&f)[L::Q], unsigned m, const T* va
   });
 }
 
+// ---- HybridBC (bc_hybrid.py:254-358; helper_functions_bc.py:160-340), kernel backends only in the reference ------------
+// f: post-streaming populations of the boundary cell (updated in place); pre: the cell's own pre-streaming populations;
+// m: missing bit-set; wgt: the q wall-distance weights of the cell as the mesh masker stored them (the weight of missing
+// direction l sits in slot opp l, bc_hybrid.py:207-214) or nullptr; val[0..2] wall velocity, val[3] != 0: moving wall.
+// method 0: interpolated bounce-back + Latt regularisation, 1: interpolated bounce-back + Grad's approximation on the
+// missing populations, 2: Tao's non-equilibrium bounce-back + regularisation.  Operation order = oracle/mesh_bc.py.
+constexpr int HYBRID_BB_REGULARIZED = 0, HYBRID_BB_GRADS = 1, HYBRID_NEQ_REGULARIZED = 2;
+
+template <class L, class T>
+__device__ __forceinline__ void hybrid_cell(T (&f)[L::Q], const T (&pre)[L::Q], unsigned m, const float* wgt, const T* val, int method) {
+  constexpr int Q = L::Q;
+  const bool moving = val[3] != T(0);
+  const T one = T(1.0);
+  T out[Q];
+  auto c_dot = [&](auto lc, const T* vec) {
+    constexpr int l = decltype(lc)::value;
+    T cu = T(0.0);
+    static_for<3>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if constexpr (L::c(a, l) == 1) cu = cu + vec[a];
+      if constexpr (L::c(a, l) == -1) cu = cu - vec[a];
+    });
+    return cu;
+  };
+  if (method != HYBRID_NEQ_REGULARIZED) {
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int o = opp<L>(l);
+      T v;
+      if (wgt) {
+        const T wl = static_cast<T>(wgt[o]);
+        v = ((one - wl) * f[o] + wl * (pre[l] + pre[o])) / (one + wl);
+      } else {
+        v = pre[o];
+      }
+      if ((m >> o) & 1u) v = pre[o];  // sandwiched between two solid cells
+      if (moving) v = v + c_dot(lc, val) * (T(6.0) * T(L::w(l)));
+      out[l] = ((m >> l) & 1u) ? v : f[l];
+    });
+  } else {
+    T rho, u[3], feq[Q], feqw[Q];
+    moments<L, T>(pre, rho, u);
+    equilibrium<L, T>(rho, u, feq);
+    if (moving) {
+      const T uw[3] = {val[0], val[1], val[2]};
+      equilibrium<L, T>(rho, uw, feqw);
+    }
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int o = opp<L>(l);
+      const T wl = wgt ? static_cast<T>(wgt[o]) : T(0.5);
+      const T fneq = pre[o] - feq[o];
+      const T fw = (moving ? feqw[l] : T(L::w(l)) * rho) + fneq;
+      out[l] = ((m >> l) & 1u) ? (fw + wl * pre[l]) / (one + wl) : f[l];
+    });
+  }
+  T rho, u[3];
+  moments<L, T>(out, rho, u);
+  if (method == HYBRID_BB_GRADS) {
+    T pi[6];
+    second_moment<L, T>(out, pi);
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      T qp = T(0);
+      static_for<n_pi<L>()>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T pk = (k == 0 || k == 3 || k == 5) ? pi[k] - rho / T(3.0) : pi[k];
+        const T t = T(qi<L>(l, k)) * pk;
+        if constexpr (k == 0)
+          qp = t;
+        else
+          qp = qp + t;
+      });
+      const T cu = c_dot(lc, u) * T(3.0);
+      const T g = (rho * T(L::w(l))) * (one + cu) + (T(L::w(l)) * T(4.5)) * qp;
+      f[l] = ((m >> l) & 1u) ? g : out[l];
+    });
+  } else {
+    T feq[Q], fneq[Q], pi[6];
+    equilibrium<L, T>(rho, u, feq);
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      fneq[l] = out[l] - feq[l];
+    });
+    second_moment<L, T>(fneq, pi);
+    static_for<Q>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      T qp = T(0);
+      static_for<n_pi<L>()>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        const T t = T(qi<L>(l, k)) * pi[k];
+        if constexpr (k == 0)
+          qp = t;
+        else
+          qp = qp + t;
+      });
+      f[l] = feq[l] + (T(4.5) * T(L::w(l))) * qp;
+    });
+  }
+}
+
 // Smagorinsky LES BGK (smagorinsky_les_bgk.py:44-60)
 template <class L, class T>
 __device__ __forceinline__ void smagorinsky(T (&f)[L::Q], const T (&feq)[L::Q], T omega, T cs) {

@@ -191,6 +191,23 @@ __global__ void k_apply_bc(int id, int kind, BcValues vals, FieldView f_pre, Fie
     });
     return;
   }
+  if (kind >= XLBHIP_BC_HYBRID_BB_REGULARIZED && kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED) {
+    if constexpr (L::D == 3) {
+      T ff[L::Q], pre[L::Q], val[5];
+      static_for<L::Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        ff[l] = load_rt<T>(f_post, (size_t)l * f_post.plane_stride + io);
+        pre[l] = load_rt<T>(f_pre, (size_t)l * f_pre.plane_stride + ip);
+      });
+      for (int a = 0; a < 5; ++a) val[a] = static_cast<T>(vals.v[a]);
+      hybrid_cell<L, T>(ff, pre, m, nullptr, val, kind - XLBHIP_BC_HYBRID_BB_REGULARIZED);
+      static_for<L::Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        store_rt<T>(f_post, (size_t)l * f_post.plane_stride + io, ff[l]);
+      });
+    }
+    return;
+  }
   static_for<L::Q>([&](auto lc) {
     constexpr int l = decltype(lc)::value;
     constexpr int o = opp<L>(l);
@@ -597,7 +614,8 @@ __global__ void k_mesh_classify(const uint8_t* solid, uint8_t* bc, uint32_t* mis
 // ---- MeshMaskerRay (boundary_masker/ray.py:38-76): a voxel whose link along c_l (from its centre, length |c_l|) crosses the
 // surface gets the BC id and missing[opp l].  One thread per triangle over the voxels around its bounding box; the
 // segment / triangle test is Moeller-Trumbore in fp32 (both faces count, like a mesh ray query).
-__device__ inline bool seg_tri_hit(const float* v, float px, float py, float pz, float dx, float dy, float dz, float max_t) {
+// closest-hit building block: true and *t_out = ray parameter when the segment p + t d, 0 <= t <= max_t, meets the triangle
+__device__ inline bool seg_tri_t(const float* v, float px, float py, float pz, float dx, float dy, float dz, float max_t, float* t_out) {
   const float e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
   const float e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
   const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
@@ -611,8 +629,24 @@ __device__ inline bool seg_tri_hit(const float* v, float px, float py, float pz,
   const float w = ((dx * qx + dy * qy) + dz * qz) * inv;
   if (w < 0.0f || u + w > 1.0f) return false;
   const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+  *t_out = t;
   return t >= 0.0f && t <= max_t;
 }
+__device__ inline bool seg_tri_hit(const float* v, float px, float py, float pz, float dx, float dy, float dz, float max_t) {
+  float t;
+  return seg_tri_t(v, px, py, pz, dx, dy, dz, max_t, &t);
+}
+template <class L, int l>
+__device__ __forceinline__ float link_len() {
+  constexpr int n2 = L::c(0, l) * L::c(0, l) + L::c(1, l) * L::c(1, l) + L::c(2, l) * L::c(2, l);
+  return n2 == 1 ? 1.0f : (n2 == 2 ? 1.41421356237309515f : 1.73205080756887719f);
+}
+// smallest ray parameter so far of link l of voxel c (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void t_min(unsigned* tbuf, size_t cells, int l, size_t c, float t) {
+  atomicMin(tbuf + (size_t)l * cells + c, __float_as_uint(t));
+}
+constexpr unsigned T_NONE = 0x7f800000u;  // +inf: no hit
+
 template <class L>
 __global__ void k_mesh_ray(const float* verts, int64_t n_tri, uint8_t* bc, uint32_t* miss, Dims d, int id) {
   const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -661,6 +695,255 @@ __global__ void k_mesh_resolve(const uint8_t* bc, uint32_t* miss, Dims d, int id
     }
   });
   if (bits != 0u) miss[c] |= bits;
+}
+
+// ---- wall distances of MeshMaskerRay (ray.py:69-76): closest hit per (voxel, link) over all triangles ----
+// One thread per triangle over the voxels around its bounding box, like k_mesh_ray; additionally the smallest ray
+// parameter of every link goes to tbuf[l][voxel] (atomicMin).  k_mesh_weights turns them into distances[l] = t / |c_l|.
+template <class L>
+__global__ void k_mesh_ray_dist(const float* verts, int64_t n_tri, uint8_t* bc, uint32_t* miss, unsigned* tbuf, Dims d, int id) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  int lo[3], hi[3];
+  const int ext[3] = {d.nx, d.ny, d.nz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 2);
+    hi[a] = min(ext[a] - 1, (int)floorf(mx) + 1);
+  }
+  const size_t cells = (size_t)d.nx * d.ny * d.nz;
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k) {
+        const float px = (float)i + 0.5f, py = (float)j + 0.5f, pz = (float)k + 0.5f;
+        const size_t c = ((size_t)i * d.ny + j) * d.nz + k;
+        unsigned bits = 0;
+        static_for<L::Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (l != opp<L>(l)) {
+            const float len = link_len<L, l>();
+            float t;
+            if (seg_tri_t(v, px, py, pz, (float)L::c(0, l) / len, (float)L::c(1, l) / len, (float)L::c(2, l) / len, len, &t)) {
+              bits |= 1u << opp<L>(l);
+              t_min(tbuf, cells, l, c, t);
+            }
+          }
+        });
+        if (bits != 0u) {
+          bc[c] = (uint8_t)id;
+          atomicOr(miss + c, bits);
+        }
+      }
+}
+// mode 0 (RAY): distances[l] = t / |c_l| where a hit was recorded
+template <class L>
+__global__ void k_mesh_weights_ray(const unsigned* tbuf, FieldView dist, Dims d) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t cells = (size_t)d.nx * d.ny * d.nz, c = ((size_t)x * d.ny + y) * d.nz + z;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l != opp<L>(l)) {
+      const unsigned tb = tbuf[(size_t)l * cells + c];
+      if (tb != T_NONE) static_cast<float*>(dist.data)[(size_t)l * dist.plane_stride + c] = __uint_as_float(tb) / link_len<L, l>();
+    }
+  });
+}
+
+// ---- MeshMaskerWinding (winding.py:46-103) ----
+// inside test: generalized winding number of the triangle soup at the voxel centre, exact (sum of the signed solid angles,
+// Van Oosterom & Strackee, fp64) instead of Warp's BVH approximation; > 0.5 = inside.  One thread per voxel of the mesh's
+// bounding box, every thread walks all triangles (the triangle data is a broadcast read).
+__global__ void k_mesh_winding(const float* verts, int64_t n_tri, uint8_t* solid, Dims d, int lo0, int lo1, int lo2, int n0, int n1, int n2) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)n0 * n1 * n2) return;
+  const int i = lo0 + (int)(t / ((int64_t)n1 * n2)), j = lo1 + (int)((t / n2) % n1), k = lo2 + (int)(t % n2);
+  const double px = i + 0.5, py = j + 0.5, pz = k + 0.5;
+  double sum = 0.0;
+  for (int64_t f = 0; f < n_tri; ++f) {
+    const float* v = verts + 9 * f;
+    const double ax = v[0] - px, ay = v[1] - py, az = v[2] - pz;
+    const double bx = v[3] - px, by = v[4] - py, bz = v[5] - pz;
+    const double cx = v[6] - px, cy = v[7] - py, cz = v[8] - pz;
+    const double la = sqrt(ax * ax + ay * ay + az * az), lb = sqrt(bx * bx + by * by + bz * bz), lc = sqrt(cx * cx + cy * cy + cz * cz);
+    const double num = ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx);
+    const double den = la * lb * lc + (ax * bx + ay * by + az * bz) * lc + (bx * cx + by * cy + bz * cz) * la + (cx * ax + cy * ay + cz * az) * lb;
+    sum += 2.0 * atan2(num, den);
+  }
+  if (sum / (4.0 * 3.14159265358979323846) > 0.5) solid[((size_t)i * d.ny + j) * d.nz + k] = 1;
+}
+// rays out of the solid voxels: one thread per triangle over the SOLID voxels around its bounding box
+template <class L>
+__global__ void k_mesh_winding_rays(const float* verts, int64_t n_tri, const uint8_t* solid, unsigned* tbuf, Dims d) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  int lo[3], hi[3];
+  const int ext[3] = {d.nx, d.ny, d.nz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 2);
+    hi[a] = min(ext[a] - 1, (int)floorf(mx) + 1);
+  }
+  const size_t cells = (size_t)d.nx * d.ny * d.nz;
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k) {
+        const size_t c = ((size_t)i * d.ny + j) * d.nz + k;
+        if (!solid[c]) continue;
+        const float px = (float)i + 0.5f, py = (float)j + 0.5f, pz = (float)k + 0.5f;
+        static_for<L::Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (l != opp<L>(l)) {
+            const float len = link_len<L, l>();
+            float t;
+            if (seg_tri_t(v, px, py, pz, (float)L::c(0, l) / len, (float)L::c(1, l) / len, (float)L::c(2, l) / len, len, &t)) t_min(tbuf, cells, l, c, t);
+          }
+        });
+      }
+}
+// tags: the fluid neighbour at +c_l of a solid voxel whose ray along c_l met the surface gets the id, missing[l] and
+// distances[opp l] = (|c_l| - t) / |c_l|; written from the NEIGHBOUR's thread (one writer per voxel); solid voxels -> BC_SOLID
+template <class L>
+__global__ void k_mesh_winding_tag(const uint8_t* solid, const unsigned* tbuf, uint8_t* bc, uint32_t* miss, FieldView dist, Dims d, int id) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t cells = (size_t)d.nx * d.ny * d.nz, c = ((size_t)x * d.ny + y) * d.nz + z;
+  if (solid[c]) {
+    bc[c] = 255;
+    return;
+  }
+  unsigned bits = 0;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l != opp<L>(l)) {
+      const int xs = x - L::c(0, l), ys = y - L::c(1, l), zs = z - L::c(2, l);  // the solid voxel whose ray along c_l reaches me
+      if (xs >= 0 && xs < d.nx && ys >= 0 && ys < d.ny && zs >= 0 && zs < d.nz) {
+        const size_t cs = ((size_t)xs * d.ny + ys) * d.nz + zs;
+        if (solid[cs]) {
+          const unsigned tb = tbuf[(size_t)l * cells + cs];
+          if (tb != T_NONE) {
+            bits |= 1u << l;
+            if (dist.data) {
+              const float len = link_len<L, l>();
+              static_cast<float*>(dist.data)[(size_t)opp<L>(l) * dist.plane_stride + c] = (len - __uint_as_float(tb)) / len;
+            }
+          }
+        }
+      }
+    }
+  });
+  if (bits != 0u) {
+    bc[c] = (uint8_t)id;
+    miss[c] |= bits;
+  }
+}
+
+// ---- MeshMaskerAABBClose (aabb_close.py:67-154, 216-263, 303-344) ----
+// AABB voxelisation on the grid padded by `pad` voxels per side (voxel (i, j, k) of the padded grid is the unit cube at
+// (i - pad, j - pad, k - pad))
+__global__ void k_mesh_solid_padded(const float* verts, int64_t n_tri, uint8_t* solid, int px, int py, int pz, int pad) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  TriBox t;
+  if (!tri_box_setup(v, t)) return;
+  int lo[3], hi[3];
+  const int ext[3] = {px, py, pz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 1 + pad);
+    hi[a] = min(ext[a] - 1, (int)floorf(mx) + pad);
+  }
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k)
+        if (tri_box_overlap(t, (float)(i - pad), (float)(j - pad), (float)(k - pad))) solid[((size_t)i * py + j) * pz + k] = 1;
+}
+// max (dilate) / min (erode) filter over the (2 h + 1)^3 cube; voxels within h of the padded grid's faces are copied
+__global__ void k_morph(const uint8_t* in, uint8_t* out, int px, int py, int pz, int h, int dilate) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)px * py * pz) return;
+  const int i = (int)(t / ((int64_t)py * pz)), j = (int)((t / pz) % py), k = (int)(t % pz);
+  if (i < h || i >= px - h || j < h || j >= py - h || k < h || k >= pz - h) {
+    out[t] = in[t];
+    return;
+  }
+  uint8_t acc = dilate ? 0 : 1;
+  for (int a = -h; a <= h; ++a)
+    for (int b = -h; b <= h; ++b)
+      for (int c = -h; c <= h; ++c) {
+        const uint8_t v = in[((size_t)(i + a) * py + (j + b)) * pz + (k + c)];
+        acc = dilate ? (acc | v) : (acc & v);
+      }
+  out[t] = acc;
+}
+// crop the padded mask to the domain
+__global__ void k_crop(const uint8_t* in, uint8_t* out, Dims d, int py, int pz, int pad) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  out[((size_t)x * d.ny + y) * d.nz + z] = in[((size_t)(x + pad) * py + (y + pad)) * pz + (z + pad)];
+}
+// closest hit within 1.5 |c_l| along c_l for the boundary voxels (bc == id) whose neighbour at +c_l is solid
+template <class L>
+__global__ void k_mesh_close_rays(const float* verts, int64_t n_tri, const uint8_t* solid, const uint8_t* bc, unsigned* tbuf, Dims d, int id) {
+  const int64_t tix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tix >= n_tri) return;
+  const float* v = verts + 9 * tix;
+  int lo[3], hi[3];
+  const int ext[3] = {d.nx, d.ny, d.nz};
+  for (int a = 0; a < 3; ++a) {
+    const float mn = fminf(v[a], fminf(v[3 + a], v[6 + a])), mx = fmaxf(v[a], fmaxf(v[3 + a], v[6 + a]));
+    lo[a] = max(0, (int)floorf(mn) - 3);  // centre within 1.5 links (<= 1.5 per axis) of the bounding box
+    hi[a] = min(ext[a] - 1, (int)floorf(mx) + 2);
+  }
+  const size_t cells = (size_t)d.nx * d.ny * d.nz;
+  for (int i = lo[0]; i <= hi[0]; ++i)
+    for (int j = lo[1]; j <= hi[1]; ++j)
+      for (int k = lo[2]; k <= hi[2]; ++k) {
+        const size_t c = ((size_t)i * d.ny + j) * d.nz + k;
+        if (bc[c] != id) continue;
+        const float px = (float)i + 0.5f, py = (float)j + 0.5f, pz = (float)k + 0.5f;
+        static_for<L::Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (l != opp<L>(l)) {
+            const int xn = i + L::c(0, l), yn = j + L::c(1, l), zn = k + L::c(2, l);
+            if (xn >= 0 && xn < d.nx && yn >= 0 && yn < d.ny && zn >= 0 && zn < d.nz && solid[((size_t)xn * d.ny + yn) * d.nz + zn]) {
+              const float len = link_len<L, l>();
+              float t;
+              if (seg_tri_t(v, px, py, pz, (float)L::c(0, l) / len, (float)L::c(1, l) / len, (float)L::c(2, l) / len, 1.5f * len, &t)) t_min(tbuf, cells, l, c, t);
+            }
+          }
+        });
+      }
+}
+// distances[l] = (t - 0.5 |c_l|) / |c_l| with a hit, 1.0 without, for every link of a boundary voxel that ends in a solid voxel
+template <class L>
+__global__ void k_mesh_weights_close(const uint8_t* solid, const uint8_t* bc, const unsigned* tbuf, FieldView dist, Dims d, int id) {
+  int x, y, z;
+  if (!cell_of_thread(d, x, y, z)) return;
+  const size_t cells = (size_t)d.nx * d.ny * d.nz, c = ((size_t)x * d.ny + y) * d.nz + z;
+  if (bc[c] != id || solid[c]) return;
+  static_for<L::Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l != opp<L>(l)) {
+      const int xn = x + L::c(0, l), yn = y + L::c(1, l), zn = z + L::c(2, l);
+      if (xn >= 0 && xn < d.nx && yn >= 0 && yn < d.ny && zn >= 0 && zn < d.nz && solid[((size_t)xn * d.ny + yn) * d.nz + zn]) {
+        const unsigned tb = tbuf[(size_t)l * cells + c];
+        const float len = link_len<L, l>();
+        static_cast<float*>(dist.data)[(size_t)l * dist.plane_stride + c] = tb == T_NONE ? 1.0f : (__uint_as_float(tb) - 0.5f * len) / len;
+      }
+    }
+  });
+}
+
+// rows of a field at listed interior cells: out[i][l] = field[l][cells[i]] (small device -> host transfers of boundary data)
+template <class E>
+__global__ void k_gather(const E* data, size_t plane_stride, size_t ghost, int card, const uint32_t* cells, int64_t n, E* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int l = 0; l < card; ++l) out[i * card + l] = data[(size_t)l * plane_stride + ghost + cells[i]];
 }
 
 // meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table:

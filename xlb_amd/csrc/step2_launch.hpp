@@ -25,6 +25,9 @@ static int launch2(const StepLaunch& p) {
   a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)
   a.prof_vals = nullptr;
   a.n_prof = 0;
+  a.dist_keys = nullptr;
+  a.dist_vals = nullptr;
+  a.n_dist = 0;
   a.ids_packed = p.ids_packed;
   a.kinds_packed = p.kinds_packed;
   a.n_bc = p.n_bc;

@@ -46,6 +46,10 @@ struct StepArgs {
   const uint32_t* prof_keys;
   const T* prof_vals;
   int n_prof;
+  // wall-distance weights of HybridBC cells (extended variant only): sorted storage cell indices and q floats per entry
+  const uint32_t* dist_keys;
+  const float* dist_vals;
+  int n_dist;
   unsigned long long ids_packed;  // up to 8 bc ids, one per byte
   unsigned kinds_packed;          // their kinds, one per nibble
   int n_bc;
@@ -332,6 +336,27 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
               val = a.prof_vals + 3 * (size_t)prof_find(a.prof_keys, a.n_prof, (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k);
             zouhe_cell<L, T>(f[k], m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
                              kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
+          } else if (kind >= XLBHIP_BC_HYBRID_BB_REGULARIZED && kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED) {
+            if constexpr (L::D == 3) {
+              // bc_hybrid.py:254-358: own pre-streaming populations, missing bits, wall velocity and (optionally) the
+              // cell's wall-distance weights from the stepper's sparse table
+              const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
+              const T* val = opaque(a.bc_values + id * 27u);
+              const unsigned cbo = opaque(cb);
+              T pre[Q];
+              static_for<Q>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                const S* own = a.src + (size_t)l * a.plane_stride + (size_t)Xs[1] * plane_cells;  // uniform
+                pre[l] = to_compute<T, S>(ld(own, cbo));
+              });
+              const float* wgt = nullptr;
+              if (val[4] != T(0) && a.n_dist > 0) {
+                const unsigned key = (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k;
+                const int slot = prof_find(a.dist_keys, a.n_dist, key);
+                if (a.dist_keys[slot] == key) wgt = a.dist_vals + (size_t)slot * Q;
+              }
+              hybrid_cell<L, T>(f[k], pre, m, wgt, val, (int)kind - XLBHIP_BC_HYBRID_BB_REGULARIZED);
+            }
           }
         }
       }

@@ -20,6 +20,9 @@ struct StepLaunch {
   const uint32_t* prof_keys;  // profile table of Zou-He / Regularized BCs (sorted storage cell indices), or nullptr
   const void* prof_vals;      // compute dtype [n_prof][3]
   int n_prof;
+  const uint32_t* dist_keys;  // wall-distance table of HybridBC cells (sorted storage cell indices), or nullptr
+  const float* dist_vals;     // [n_dist][q]
+  int n_dist;
   unsigned long long ids_packed;
   unsigned kinds_packed;
   int n_bc;
@@ -71,6 +74,9 @@ int launch_typed(const StepLaunch& p) {
   a.prof_keys = p.prof_keys;
   a.prof_vals = static_cast<const T*>(p.prof_vals);
   a.n_prof = p.n_prof;
+  a.dist_keys = p.dist_keys;
+  a.dist_vals = p.dist_vals;
+  a.n_dist = p.n_dist;
   a.ids_packed = p.ids_packed;
   a.kinds_packed = p.kinds_packed;
   a.n_bc = p.n_bc;

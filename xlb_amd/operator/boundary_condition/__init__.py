@@ -9,4 +9,5 @@ from .boundary_condition import (
     ZouHeBC as ZouHeBC,
     RegularizedBC as RegularizedBC,
     ExtrapolationOutflowBC as ExtrapolationOutflowBC,
+    HybridBC as HybridBC,
 )

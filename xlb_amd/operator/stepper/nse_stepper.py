@@ -75,6 +75,12 @@ class IncompressibleNavierStokesStepper(Stepper):
                 table = bc._profile_table(self.grid) if hasattr(bc, "_profile_table") else None
                 if table is not None:
                     self._native.set_bc_profile(bc.id, *table)
+            for bc in self.boundary_conditions:
+                table = getattr(bc, "_distance_table", None)
+                if table is not None:
+                    # wall-distance weights the mesh masker gathered (HybridBC with use_mesh_distance); interior linear
+                    # cell index == storage cell index on the single-rank fields mesh BCs live on
+                    self._native.set_bc_distances(*table)
             if self.force_vector is not None:
                 f3 = np.zeros(3)
                 f3[3 - self.velocity_set.d :] = self.force_vector  # internal 3-component form
@@ -98,18 +104,13 @@ class IncompressibleNavierStokesStepper(Stepper):
         with_indices = [bc for bc in boundary_conditions if getattr(bc, "indices", None) is not None]
         if with_indices:
             bc_mask, missing_mask = masker(with_indices, bc_mask, missing_mask)
-        # mesh-based BCs (nse_stepper.py:165-203 in the reference): AABB voxelisation only
+        # mesh-based BCs (nse_stepper.py:165-203 in the reference): one masker per voxelisation method
         for bc in boundary_conditions:
             if getattr(bc, "mesh_vertices", None) is None:
                 continue
-            from ..boundary_masker import MeshMaskerAABB, MeshMaskerRay
+            from ..boundary_masker import mesh_masker_for
 
-            method = getattr(bc, "voxelization_method", None)
-            name = "AABB" if method is None else getattr(method, "name", "AABB")
-            if name not in ("AABB", "RAY"):
-                raise NotImplementedError(f"voxelization method {name}: AABB and RAY are built on the HIP backend")
-            masker_cls = MeshMaskerAABB if name == "AABB" else MeshMaskerRay
-            mesh_masker = masker_cls(self.velocity_set, self.precision_policy, self.compute_backend)
+            mesh_masker = mesh_masker_for(getattr(bc, "voxelization_method", None), self.velocity_set, self.precision_policy, self.compute_backend)
             f_1, bc_mask, missing_mask = mesh_masker(bc, f_1, bc_mask, missing_mask)
         return f_1, bc_mask, missing_mask
 
