@@ -154,6 +154,8 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
+  c->opts["fuse2_xcap"] = 8;       // with fuse2_clean: planes of the thin first / last x-segment (0 = uniform cuts)
+  c->opts["fuse2_clean"] = 1;      // two-step kernel with BCs: work items without boundary cells run the BC-free body (same launch)
   c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
@@ -984,6 +986,9 @@ struct xlbhip_stepper {
   int order_ty = 0, order_tz = 0, order_mode = -1;
   uint32_t* meta = nullptr;  // two-step kernel: id | missing << 8, rebuilt by every xlbhip_run that fuses
   size_t meta_cells = 0;
+  // two-step kernel: per launch geometry (x_begin, x_count, segments, tile order?, swizzle) the per-block "no boundary
+  // cell" flags; dropped whenever the meta words are rebuilt
+  std::map<std::array<int, 5>, uint8_t*> clean_cache;
   bool forced = false;
   double force[3] = {0, 0, 0};
   double smag_cs = 0.17;
@@ -1066,8 +1071,10 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.bc = (s->n_bc > 0 && bcm) ? static_cast<const uint8_t*>(bcm->data) : nullptr;
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
   p.meta = nullptr;
+  p.clean = nullptr;
   p.tile_order = nullptr;
   p.x_segments = 1;
+  p.x_cap = 0;
   p.tile_ty = fuse2_tile_ty(c);
   p.tile_tz = fuse2_tile_tz(c);
   p.tab_kind = s->tab_kind;
@@ -1125,12 +1132,16 @@ static int fuse2_segments(const xlbhip_stepper* s, const StepLaunch& p) {
     return n;
   }
   const long tiles = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz), cus = fill_cus(s->ctx);
+  // with boundary conditions finer items win twice: the expensive hull tiles balance better (halfway walls), and work
+  // items free of boundary cells — most segments of an interior tile column — run the BC-free body (fuse2_clean):
+  // take the most segments of >= 32 planes (measured at 256^3 ... 512^3: profiles/r01/sweeps.md, profiles/r02/step2_sweeps.txt)
+  const bool finest = s->needs_missing || (p.has_bc && opt(s->ctx, "fuse2_clean", 1));
   int best = 1;
   long best_cost = -1;
   for (int n = 1; n <= 8; n *= 2) {
     if (n > 1 && p.x_count / n < 32) break;
     const long cost = ((tiles * n + cus - 1) / cus) * (p.x_count / n + 3);
-    if (best_cost < 0 || cost < best_cost || s->needs_missing) {
+    if (best_cost < 0 || cost < best_cost || finest) {
       best = n;
       best_cost = cost;
     }
@@ -1157,8 +1168,29 @@ static int outflow_aux(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field*
 }
 
 static int launch_any(const xlbhip_stepper* s, const StepLaunch& p);
-static int launch_step2(const xlbhip_stepper* s, const StepLaunch& p) {
-  return s->lattice == XLBHIP_D3Q27 ? launch_step2_d3q27_bgk(p) : launch_step2_d3q19_bgk(p);
+static void drop_clean_cache(xlbhip_stepper* s) {
+  for (auto& kv : s->clean_cache) (void)hipFree(kv.second);
+  s->clean_cache.clear();
+}
+
+static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
+  if (s->lattice == XLBHIP_D3Q27) return launch_step2_d3q27_bgk(p);
+  p.clean = nullptr;
+  if (p.has_bc && p.meta && opt(s->ctx, "fuse2_clean", 1)) {
+    const std::array<int, 5> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, p.tile_order ? 1 : 0, p.xcd_swizzle};
+    auto it = s->clean_cache.find(key);
+    if (it == s->clean_cache.end()) {
+      uint8_t* flags = nullptr;
+      XLB_HIP(hipMalloc(&flags, (size_t)step2_items(p)));
+      if (int rc = step2_build_clean(p, flags)) {
+        (void)hipFree(flags);
+        return rc;
+      }
+      it = s->clean_cache.emplace(key, flags).first;
+    }
+    p.clean = it->second;
+  }
+  return launch_step2_d3q19_bgk(p);
 }
 
 // Pair of steps for a stepper whose Zou-He / Regularized / outflow cells all sit in the planes x = 0 and x = nx - 1
@@ -1199,8 +1231,10 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   // hull tiles first only pays when they are much more expensive than fluid tiles (halfway walls: redirected
   // loads); with fullway / equilibrium boundaries the XCD-compact order is faster (fuse2_lpt: 0 never, 1 auto, 2 always)
   const int64_t lpt = opt(s->ctx, "fuse2_lpt", 1);
-  p.tile_order = (p.has_bc && (lpt >= 2 || (lpt == 1 && s->needs_missing))) ? s->tile_order : nullptr;
+  const bool clean_on = p.has_bc && opt(s->ctx, "fuse2_clean", 1) != 0;
+  p.tile_order = (p.has_bc && (lpt >= 2 || (lpt == 1 && (s->needs_missing || clean_on)))) ? s->tile_order : nullptr;
   p.x_segments = fuse2_segments(s, p);
+  p.x_cap = clean_on ? (int)opt(s->ctx, "fuse2_xcap", 8) : 0;
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
   if (s->edge_ext_ok) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
@@ -1352,6 +1386,7 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     s->order_ty = tys;
     s->order_tz = tzs;
   }
+  drop_clean_cache(s);  // (stream-ordered: the flags' last readers were enqueued before this point and hipFree synchronises)
   hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, c->stream, static_cast<const uint8_t*>(bcm->data),
                      miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,
                      s->moving_mask);
@@ -1580,6 +1615,7 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   if (s->scratch) xlbhip_field_destroy(s->scratch);
   if (s->meta) (void)hipFree(s->meta);
   if (s->tile_order) (void)hipFree(s->tile_order);
+  drop_clean_cache(s);
   delete s;
   return 0;
 }

@@ -715,7 +715,12 @@ __device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, co
     });
     static_for<G>([&](auto kc) {
       constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
-      p[k] = f32x2{f[l], f[opp<L>(l)]};
+      // (two separately pinned scalars: hipcc otherwise fuses the two adjacent array elements into ONE <2 x float> load of
+      // f[], which keeps that slice of the array in memory — scratch — whenever the backend cannot promote it any more)
+      float pa = f[l], pb = f[opp<L>(l)];
+      launder(pa);
+      launder(pb);
+      p[k] = f32x2{pa, pb};
       t[k] = p[k] - t[k];  // fneq
     });
     static_for<G>([&](auto kc) { constexpr int k = decltype(kc)::value; t[k] = om2 * t[k]; });
@@ -801,8 +806,15 @@ __device__ __forceinline__ void collide(T (&f)[L::Q], T omega, const CollideExtr
 // measured 4 % slower with it: it stays on collide<>)
 template <class L, int GMAX>
 __device__ __forceinline__ void collide_bgk_packed(float (&f)[L::Q], float omega) {
-  float rho, u[3];
-  moments<L, float>(f, rho, u);
+  float rho, um[3];
+  moments<L, float>(f, rho, um);
+  // (pinning the three components in registers keeps hipcc from parking u[] in scratch and re-loading overlapping pairs of
+  // it when two instantiations of the two-step body share one kernel)
+  float u0 = um[0], u1 = um[1], u2 = um[2];
+  launder(u0);
+  launder(u1);
+  launder(u2);
+  const float u[3] = {u0, u1, u2};
   bgk_packed_pairs<L, GMAX>(f, rho, u, omega);
 }
 

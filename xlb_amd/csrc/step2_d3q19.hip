@@ -35,4 +35,21 @@ int launch_step2_d3q19_bgk(const StepLaunch& p) {
   return p.has_bc ? launch2<D3Q19, 1, 8, 64, false>(p) : launch2<D3Q19, 0, 8, 64, false>(p);
 }
 
+// per-block "no boundary cell in this work item" flags for the launch geometry of p (n = tiles x effective segments bytes)
+int step2_build_clean(const StepLaunch& p, uint8_t* out) {
+  XLB_REQUIRE(p.meta && out && p.tile_ty == 8 && p.tile_tz == 64, "clean flags: (8 x 64) tiles with meta words only");
+  const size_t ghost = (size_t)p.halo * p.ny * p.nz;
+  const unsigned tiles = (unsigned)(p.ny / 8) * (unsigned)(p.nz / 64);
+  const int segs = step2_eff_segments(p), swz = step2_eff_swizzle(p, tiles);
+  if (p.halo)
+    hipLaunchKernelGGL((k_step2_clean<8, 64, true>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta + ghost, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
+                       p.x_count, p.nx, p.ny, p.nz, out);
+  else
+    hipLaunchKernelGGL((k_step2_clean<8, 64, false>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
+                       p.x_count, p.nx, p.ny, p.nz, out);
+  XLB_HIP(hipGetLastError());
+  return 0;
+}
+int step2_items(const StepLaunch& p) { return (p.ny / p.tile_ty) * (p.nz / p.tile_tz) * step2_eff_segments(p); }
+
 }  // namespace xlb

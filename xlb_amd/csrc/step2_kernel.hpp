@@ -22,6 +22,9 @@
 #ifndef XLB_STEP2_ALIGN
 #define XLB_STEP2_ALIGN 256
 #endif
+#ifndef XLB_STEP2_CLEAN_GMAX
+#define XLB_STEP2_CLEAN_GMAX 3  // pair-group width of the BC-free body inside the BC kernel (1 makes hipcc park the pairs in scratch there)
+#endif
 
 namespace xlb {
 
@@ -116,18 +119,32 @@ __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id
 // plane 0, so that plane indices -2 .. nx + 1 address the ghosts directly and x never wraps.  (A compile-time
 // switch: the kernel sits at the SGPR limit — 19 uniform row bases per plane — and a run-time halo offset pushed
 // it into scratch spills, which also broke the hand-counted vmcnt of the fix-up loads.)
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED>
-__global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
+// planes [x_lo, x_hi) of segment `seg` of a tile column.  Uniform cuts, or — x_cap > 0, at least 3 segments — thin first and
+// last segments of x_cap planes: with walls on the x faces only those two segments of an interior tile column contain
+// boundary cells, and everything else of the column runs the BC-free body (k_step2 below).
+__device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_seg, int x_cap, int seg, int& x_lo, int& x_hi) {
+  if (x_cap > 0 && n_seg >= 3) {
+    const int inner = x_count - 2 * x_cap, m = n_seg - 2;
+    x_lo = seg == 0 ? x_begin : x_begin + x_cap + (int)(((long)inner * (seg - 1)) / m);
+    x_hi = seg == 0 ? x_begin + x_cap : (seg == n_seg - 1 ? x_begin + x_count : x_begin + x_cap + (int)(((long)inner * seg) / m));
+    if (seg == n_seg - 1) x_lo = x_begin + x_count - x_cap;
+  } else {
+    x_lo = x_begin + (int)(((long)x_count * seg) / n_seg);
+    x_hi = x_begin + (int)(((long)x_count * (seg + 1)) / n_seg);
+  }
+}
+
+// The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
+// run either boundary-condition form of the body in the same allocation).
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX>
+__device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsigned* ldsmeta, T* bcval) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
   static_assert(sizeof(T) == 4, "k_step2 keeps f(t+1) as fp32 in LDS");
-  __shared__ T lds[R::PLANES * NE];                      // [population-plane of the ring][cell]  (D3Q19, 8x64 tile: 100 320 B)
-  __shared__ unsigned ldsmeta[HASBC ? 3 * NE : 1];       // [slot][cell] id | missing << 8 of the f(t+1) cells
-  __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];     // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   // first cell of the buffer that holds population l of plane q (q counted from x_lo - 1; uniform)
-  auto ring = [&](auto lc, int q) -> int {
+  auto ring = [&](auto lc, int q) __attribute__((always_inline)) -> int {
     constexpr int l = decltype(lc)::value;
     if constexpr (!PACKED) {
       return (q % 3) * (Q * NE) + l * NE;
@@ -153,7 +170,8 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
     tile = (slot_in_seg % 8u) * per_xcd + slot_in_seg / 8u;
   }
   const int n_seg = a.x_segments > 0 ? a.x_segments : 1;
-  const int x_lo = a.x_begin + (int)(((long)a.x_count * seg) / n_seg), x_hi = a.x_begin + (int)(((long)a.x_count * (seg + 1)) / n_seg);
+  int x_lo, x_hi;
+  step2_seg_range(a.x_begin, a.x_count, n_seg, a.x_cap, (int)seg, x_lo, x_hi);
   const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
   const int t = threadIdx.x;
   const int nx = a.nx, ny = a.ny, nz = a.nz;
@@ -199,7 +217,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
 
   // logical plane p -> the plane phase A works on: without ghost planes x is periodic; with them planes past x_hi
   // are prefetches whose results are discarded (clamped, so that they stay inside the allocation)
-  auto wrapx = [&](int p) {
+  auto wrapx = [&](int p) __attribute__((always_inline)) {
     if constexpr (SLAB) {
       return p > x_hi ? x_hi : p;
     } else {
@@ -208,12 +226,12 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
     }
   };
   const ptrdiff_t pc = (ptrdiff_t)plane_cells;
-  auto meta_load = [&](int plane, unsigned cell) -> unsigned { return (a.meta + (ptrdiff_t)plane * pc)[cell]; };
+  auto meta_load = [&](int plane, unsigned cell) __attribute__((always_inline)) -> unsigned { return (a.meta + (ptrdiff_t)plane * pc)[cell]; };
 
-  auto finish = [&](T(&f)[Q], bool fullway) {
+  auto finish = [&](T(&f)[Q], bool fullway) __attribute__((always_inline)) {
     if (!fullway) {
       if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4)
-        collide_bgk_packed<L, (HASBC != 0 ? 3 : 1)>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp)
+        collide_bgk_packed<L, GMAX>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp); GMAX: measured best 3 / 1 (with / without BCs)
       else
         collide<L, T, COLL>(f, a.omega, a.extra);
     } else {
@@ -233,7 +251,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   // Boundary lanes redirect a pull: a halfway wall reads the own cell's OPPOSITE population for its missing
   // directions, a do-nothing cell its own populations — same register, same number of loads, nothing
   // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
-  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) {
+  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) __attribute__((always_inline)) {
     mall = 0;
     if constexpr (HASBC != 0) {
       const unsigned kind_ = meta_kind(w);
@@ -285,7 +303,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
     }
   };
   // boundary kinds that replace whole cells (halfway walls are handled where the pulls are redirected)
-  auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) {
+  auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) __attribute__((always_inline)) {
     const unsigned kind = meta_kind(w);
     if (kind == K_EQ) {
       const T* val = bcval + opaque(meta_slot(w) * 32u);
@@ -298,7 +316,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   // population) + the moving-wall term; the reference adds its 0.0 term for no-slip walls too (bc_halfway_bounce_back.py:116-134).
   // Branch-free over the wave: BRANCHES, not arithmetic, made boundary waves slow (z-face tiles cost 2.25x a fluid tile
   // with per-population scalar branches in four places).  any_moving is wave-uniform.
-  auto hw_apply = [&](T(&f)[Q], const T(&got)[Q], unsigned mm, unsigned w, bool any_moving) {
+  auto hw_apply = [&](T(&f)[Q], const T(&got)[Q], unsigned mm, unsigned w, bool any_moving) __attribute__((always_inline)) {
     if (!any_moving) {
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
@@ -317,7 +335,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
   // q: plane counted from x_lo - 1 (ring buffers q & 1 and q % 3; meta slot q % 3)
-  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int q, bool steady) {
+  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int q, bool steady) __attribute__((always_inline)) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
@@ -376,7 +394,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
 
   // phase B: f(t+2) on plane x from the ring (planes x-1, x, x+1) -> global (Q unconditional stores)
   // d = x - x_lo: plane x is plane q = d + 1 of the ring
-  auto phase_b_compute = [&](T(&f)[Q], int d) {
+  auto phase_b_compute = [&](T(&f)[Q], int d) __attribute__((always_inline)) {
     const int q0 = d + 1;  // plane x; the pull of population l comes from plane q0 - c_x(l)
     unsigned w = 0;
     if constexpr (HASBC != 0) w = ldsmeta[(q0 % 3) * NE + ctr_b];
@@ -436,7 +454,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   // the end of the buffer) makes hipcc's vmcnt model exact — with the stores inside `if (act_b)` it waits for the
   // prefetched pulls with vmcnt(19)...vmcnt(1), i.e. drains the wave's own stores every plane — but ran 9 % SLOWER
   // without boundary conditions and the same with them: the kernel is bound by VALU issue, not by these waits.
-  auto phase_b = [&](int x, int d) {
+  auto phase_b = [&](int x, int d) __attribute__((always_inline)) {
     if (!act_b) return;  // whole waves (NB % 64 == 0)
     T f[Q];
     phase_b_compute(f, d);
@@ -474,6 +492,67 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
     issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
     lds_barrier();  // plane x + 2 visible
   }
+}
+
+// Work items (tile column x x-segment) WITHOUT a single boundary cell in their grown tile and plane range run the body
+// compiled without boundary conditions — no meta words, no wave unions, the leaner schedule — inside the same launch:
+// `a.clean[blockIdx.x]` (k_step2_clean, rebuilt with the meta words every run) is block-uniform.  On the 512^3 cavity that
+// is every segment of an interior tile column but its first and last one, 54 % of the items.  (Round 1 tried the same
+// split as separate launches on two streams and lost to launch tails / kernel mixing; one launch has neither.)
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED>
+__global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
+  using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
+  using R = S2Ring<L, HASBC, PACKED>;
+  __shared__ T lds[R::PLANES * G::NE];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
+  __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
+  __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
+  if constexpr (HASBC != 0) {
+    if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
+      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX>(a, lds, ldsmeta, bcval);
+      return;
+    }
+  }
+  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : 1)>(a, lds, ldsmeta, bcval);
+}
+
+// clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel
+// visits them — carries a boundary condition.  Same block -> (tile, segment) mapping as k_step2; one block per item.
+template <int TY, int TZ, bool SLAB>
+__global__ void k_step2_clean(const uint32_t* meta /*advanced to interior plane 0 when SLAB*/, const uint32_t* tile_order, int xcd_swizzle, int x_segments,
+                              int x_cap, int x_begin, int x_count, int nx, int ny, int nz, uint8_t* clean) {
+  constexpr int EY = TY + 2, EZ = TZ + 2, NE = EY * EZ;
+  const unsigned tiles_z = (unsigned)nz / TZ, tiles_y = (unsigned)ny / TY, n_tiles = tiles_y * tiles_z;
+  const unsigned seg = blockIdx.x / n_tiles, slot_in_seg = blockIdx.x % n_tiles;
+  unsigned tile = slot_in_seg;
+  if (tile_order) {
+    tile = tile_order[slot_in_seg];
+  } else if (xcd_swizzle) {
+    const unsigned per_xcd = n_tiles / 8u;
+    tile = (slot_in_seg % 8u) * per_xcd + slot_in_seg / 8u;
+  }
+  const int n_seg = x_segments > 0 ? x_segments : 1;
+  int x_lo, x_hi;
+  step2_seg_range(x_begin, x_count, n_seg, x_cap, (int)seg, x_lo, x_hi);
+  const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
+  const ptrdiff_t pc = (ptrdiff_t)ny * nz;
+  int dirty = 0;
+  for (int p = x_lo - 1; p <= x_hi + 1; ++p) {
+    int xp = p;
+    if constexpr (SLAB) {
+      xp = p > x_hi ? x_hi : p;
+    } else {
+      xp %= nx;
+      xp = xp < 0 ? xp + nx : xp;
+    }
+    for (int t = threadIdx.x; t < NE; t += blockDim.x) {
+      int y = ty0 - 1 + t / EZ, z = tz0 - 1 + t % EZ;
+      y = y < 0 ? y + ny : (y >= ny ? y - ny : y);
+      z = z < 0 ? z + nz : (z >= nz ? z - nz : z);
+      dirty |= (meta + (ptrdiff_t)xp * pc)[(size_t)y * nz + z] != 0u;
+    }
+  }
+  dirty = __syncthreads_or(dirty);
+  if (threadIdx.x == 0) clean[blockIdx.x] = dirty ? 0 : 1;
 }
 
 }  // namespace xlb

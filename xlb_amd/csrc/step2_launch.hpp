@@ -8,6 +8,15 @@ namespace xlb {
 #ifndef XLB_STEP2_PACKED_DEFAULT
 #define XLB_STEP2_PACKED_DEFAULT false
 #endif
+// effective launch geometry (shared by the kernel launch and the clean-flag pass: both must map blocks alike)
+inline int step2_eff_segments(const StepLaunch& p) { return (p.x_segments > 1 && p.x_count >= 8 * p.x_segments) ? p.x_segments : 1; }
+// thin end segments need >= 3 segments and inner segments of at least 8 planes
+inline int step2_eff_cap(const StepLaunch& p) {
+  const int n = step2_eff_segments(p);
+  return (p.x_cap > 0 && n >= 3 && p.x_count - 2 * p.x_cap >= 8 * (n - 2)) ? p.x_cap : 0;
+}
+inline int step2_eff_swizzle(const StepLaunch& p, unsigned tiles) { return (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0; }
+
 template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED = XLB_STEP2_PACKED_DEFAULT>
 static int launch2(const StepLaunch& p) {
   StepArgs<float, float> a;
@@ -19,7 +28,9 @@ static int launch2(const StepLaunch& p) {
   a.miss = p.miss;
   a.meta = p.meta ? p.meta + ghost : nullptr;
   a.tile_order = p.tile_order;
-  a.x_segments = (p.x_segments > 1 && p.x_count >= 8 * p.x_segments) ? p.x_segments : 1;
+  a.clean = (HASBC != 0) ? p.clean : nullptr;
+  a.x_segments = step2_eff_segments(p);
+  a.x_cap = step2_eff_cap(p);
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const float*>(p.tab_values);
   a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)
@@ -43,7 +54,7 @@ static int launch2(const StepLaunch& p) {
   a.extra.force[0] = a.extra.force[1] = a.extra.force[2] = 0.0;
   a.extra.smag_cs = p.smag_cs;
   const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
-  a.xcd_swizzle = (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0;
+  a.xcd_swizzle = step2_eff_swizzle(p, tiles);
   hipLaunchKernelGGL((k_step2<L, float, float, XLBHIP_BGK, HASBC, TY, TZ, SLAB, PACKED>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
   XLB_HIP(hipGetLastError());
   return 0;

@@ -38,7 +38,9 @@ struct StepArgs {
   const uint32_t* miss;   // (nx+2h, ny, nz) bit-sets or nullptr
   const uint32_t* tile_order;  // two-step kernel only: block -> tile, or nullptr
   int x_segments;              // two-step kernel only: x cuts per tile column (>= 1)
+  int x_cap;                   // two-step kernel only: > 0: the first and last segment are x_cap planes thin (>= 3 segments)
   const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
+  const uint8_t* clean;   // two-step kernel only: per block, 1 = no boundary cell in its work item (k_step2_clean), or nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
   const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS
   // per-cell prescribed values of Zou-He / Regularized BCs built with a profile (extended variant only): sorted

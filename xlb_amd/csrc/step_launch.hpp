@@ -13,7 +13,9 @@ struct StepLaunch {
   const uint32_t* miss;
   const uint32_t* meta;  // two-step kernel only
   const uint32_t* tile_order;  // two-step kernel only
+  const uint8_t* clean;        // two-step kernel only: per-block "no boundary cells" flags for THIS launch geometry, or nullptr
   int x_segments;              // two-step kernel only
+  int x_cap;                   // two-step kernel only: thin first / last segment (planes), 0 = uniform cuts
   int tile_ty, tile_tz;        // two-step kernel only: tile of the (y, z) plane a block owns
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
@@ -67,8 +69,10 @@ int launch_typed(const StepLaunch& p) {
   a.bc = p.bc;
   a.miss = p.miss;
   a.meta = nullptr;
+  a.clean = nullptr;
   a.tile_order = nullptr;
   a.x_segments = 1;
+  a.x_cap = 0;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const T*>(p.tab_values);
   a.prof_keys = p.prof_keys;
@@ -185,6 +189,8 @@ int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
 int launch_step2_d3q27_bgk(const StepLaunch& p);
+int step2_build_clean(const StepLaunch& p, uint8_t* out);
+int step2_items(const StepLaunch& p);
 int launch_step_d2q9_ext(const StepLaunch& p, int coll);
 int launch_step_d3q19_ext(const StepLaunch& p, int coll);
 int launch_step_d3q27_ext(const StepLaunch& p, int coll);
