@@ -154,6 +154,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_xseg"] = 0;       // x segments per tile column in the two-step kernel (0 = auto: 4, fewer for short domains)
   c->opts["fuse2_lpt"] = 1;        // two-step kernel with BCs: hull tiles first (longest-processing-time-first dispatch)
   c->opts["fuse2_xcd"] = 1;        // compact tile patch per XCD in the two-step kernel
+  c->opts["fuse2_shift"] = 1;      // two-step kernel with BCs: tiling shifted by half a tile (both walls of an axis in ONE wrapping tile row)
   c->opts["fuse2_xcap"] = 8;       // with fuse2_clean: planes of the thin first / last x-segment (0 = uniform cuts)
   c->opts["fuse2_clean"] = 1;      // two-step kernel with BCs: work items without boundary cells run the BC-free body (same launch)
   c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
@@ -1075,6 +1076,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.tile_order = nullptr;
   p.x_segments = 1;
   p.x_cap = 0;
+  p.tile_oy = p.tile_oz = 0;
   p.tile_ty = fuse2_tile_ty(c);
   p.tile_tz = fuse2_tile_tz(c);
   p.tab_kind = s->tab_kind;
@@ -1177,7 +1179,7 @@ static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
   if (s->lattice == XLBHIP_D3Q27) return launch_step2_d3q27_bgk(p);
   p.clean = nullptr;
   if (p.has_bc && p.meta && opt(s->ctx, "fuse2_clean", 1)) {
-    const std::array<int, 5> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, p.tile_order ? 1 : 0, p.xcd_swizzle};
+    const std::array<int, 5> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, (p.tile_order ? 1 : 0) + 2 * p.tile_oy + 1024 * p.tile_oz, p.xcd_swizzle};
     auto it = s->clean_cache.find(key);
     if (it == s->clean_cache.end()) {
       uint8_t* flags = nullptr;
@@ -1235,6 +1237,10 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   p.tile_order = (p.has_bc && (lpt >= 2 || (lpt == 1 && (s->needs_missing || clean_on)))) ? s->tile_order : nullptr;
   p.x_segments = fuse2_segments(s, p);
   p.x_cap = clean_on ? (int)opt(s->ctx, "fuse2_xcap", 8) : 0;
+  if (p.has_bc && opt(s->ctx, "fuse2_shift", 1)) {  // half-tile shift: both walls of an axis in one (wrapping) tile row
+    p.tile_oy = p.tile_ty / 2;
+    p.tile_oz = p.tile_tz / 2;
+  }
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
   if (s->edge_ext_ok) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
@@ -1312,7 +1318,9 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // steps are faster (256^3, 53 % hull tiles: fused 41.7 vs 38.2 GLUPS; thinner domains lose)
     if (s->needs_missing) {
       const long tys = p.ny / p.tile_ty, tzs = p.nz / p.tile_tz;
-      const long hull = tys * tzs - (tys > 2 ? tys - 2 : 0) * (tzs > 2 ? tzs - 2 : 0);
+      // (with the half-tile shift both walls of an axis share one tile row: tys + tzs - 1 hull tiles)
+      const long hull = opt(s->ctx, "fuse2_shift", 1) ? std::min(tys * tzs, tys + tzs - 1)
+                                                      : tys * tzs - (tys > 2 ? tys - 2 : 0) * (tzs > 2 ? tzs - 2 : 0);
       if (hull * 100 > tys * tzs * 60) return false;
     }
   }
@@ -1332,14 +1340,21 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     s->meta_cells = cells;
   }
   const int tys = bcm->ny / fuse2_tile_ty(c), tzs = bcm->nz / fuse2_tile_tz(c);
-  const int order_mode = opt(c, "fuse2_lpt", 1) == 3 ? 3 : 0;
+  const bool shifted = opt(c, "fuse2_shift", 1) != 0;
+  const int order_mode = (opt(c, "fuse2_lpt", 1) == 3 ? 3 : 0) + (shifted ? 8 : 0);
   if (s->order_ty != tys || s->order_tz != tzs || s->order_mode != order_mode) {
     s->order_mode = order_mode;
     // hull tiles first (the expensive ones when there are walls), then the interior; both lists are dealt so that every
     // XCD (block i runs on XCD i % 8) works on a CONTIGUOUS run of tiles — neighbours share their halo rows / lines
     // through that XCD's L2 (fuse2_lpt = 3: the hull in row-major order as in round 1, for A/B)
     std::vector<uint32_t> hull, inner;
-    if (opt(c, "fuse2_lpt", 1) == 3) {
+    if (shifted) {
+      // half-tile shift: the walls of the y / z faces sit in the LAST tile row / column (the ones that wrap around)
+      for (int tz = 0; tz < tzs; ++tz) hull.push_back((uint32_t)((tys - 1) * tzs + tz));
+      for (int ty = tys - 2; ty >= 0; --ty) hull.push_back((uint32_t)(ty * tzs + tzs - 1));
+      for (int ty = 0; ty < tys - 1; ++ty)
+        for (int tz = 0; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
+    } else if (opt(c, "fuse2_lpt", 1) == 3) {
       for (int ty = 0; ty < tys; ++ty)
         for (int tz = 0; tz < tzs; ++tz)
           if (ty == 0 || ty == tys - 1 || tz == 0 || tz == tzs - 1) hull.push_back((uint32_t)(ty * tzs + tz));
@@ -1352,8 +1367,9 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
         for (int tz = tzs - 1; tz >= 0; --tz) hull.push_back((uint32_t)((tys - 1) * tzs + tz));
       for (int ty = tys - 2; ty >= 1; --ty) hull.push_back((uint32_t)(ty * tzs));
     }
-    for (int ty = 1; ty < tys - 1; ++ty)
-      for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
+    if (!shifted)
+      for (int ty = 1; ty < tys - 1; ++ty)
+        for (int tz = 1; tz < tzs - 1; ++tz) inner.push_back((uint32_t)(ty * tzs + tz));
     std::vector<uint32_t> order;
     order.reserve((size_t)tys * tzs);
     auto deal = [&](const std::vector<uint32_t>& list, bool chunked) {

@@ -663,7 +663,7 @@ constexpr int pair_first(int k) {
     }
   return -1;
 }
-template <class L, int GMAX>
+template <class L, int GMAX, bool PIN = false>
 __device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, const float (&u)[3], float omega) {
   const float usqr = usqr_of<L, float>(u);
   f32x2 U[3];
@@ -717,9 +717,12 @@ __device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, co
       constexpr int k = decltype(kc)::value, l = pair_first<L>(g0 + k);
       // (two separately pinned scalars: hipcc otherwise fuses the two adjacent array elements into ONE <2 x float> load of
       // f[], which keeps that slice of the array in memory — scratch — whenever the backend cannot promote it any more)
+      // PIN: pinned where two instantiations of the two-step body share one kernel; elsewhere it costs ~5 %)
       float pa = f[l], pb = f[opp<L>(l)];
-      launder(pa);
-      launder(pb);
+      if constexpr (PIN) {
+        launder(pa);
+        launder(pb);
+      }
       p[k] = f32x2{pa, pb};
       t[k] = p[k] - t[k];  // fneq
     });
@@ -804,10 +807,14 @@ __device__ __forceinline__ void collide(T (&f)[L::Q], T omega, const CollideExtr
 
 // moments + packed-pair BGK: what the VALU-bound two-step kernel calls (the single-step kernel is HBM-bound and was
 // measured 4 % slower with it: it stays on collide<>)
-template <class L, int GMAX>
+template <class L, int GMAX, bool PIN = false>
 __device__ __forceinline__ void collide_bgk_packed(float (&f)[L::Q], float omega) {
   float rho, um[3];
   moments<L, float>(f, rho, um);
+  if constexpr (!PIN) {
+    bgk_packed_pairs<L, GMAX, false>(f, rho, um, omega);
+    return;
+  }
   // (pinning the three components in registers keeps hipcc from parking u[] in scratch and re-loading overlapping pairs of
   // it when two instantiations of the two-step body share one kernel)
   float u0 = um[0], u1 = um[1], u2 = um[2];
@@ -815,7 +822,7 @@ __device__ __forceinline__ void collide_bgk_packed(float (&f)[L::Q], float omega
   launder(u1);
   launder(u2);
   const float u[3] = {u0, u1, u2};
-  bgk_packed_pairs<L, GMAX>(f, rho, u, omega);
+  bgk_packed_pairs<L, GMAX, true>(f, rho, u, omega);
 }
 
 }  // namespace xlb

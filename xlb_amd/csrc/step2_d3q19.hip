@@ -43,10 +43,10 @@ int step2_build_clean(const StepLaunch& p, uint8_t* out) {
   const int segs = step2_eff_segments(p), swz = step2_eff_swizzle(p, tiles);
   if (p.halo)
     hipLaunchKernelGGL((k_step2_clean<8, 64, true>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta + ghost, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
-                       p.x_count, p.nx, p.ny, p.nz, out);
+                       p.x_count, p.nx, p.ny, p.nz, p.tile_oy, p.tile_oz, out);
   else
     hipLaunchKernelGGL((k_step2_clean<8, 64, false>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
-                       p.x_count, p.nx, p.ny, p.nz, out);
+                       p.x_count, p.nx, p.ny, p.nz, p.tile_oy, p.tile_oz, out);
   XLB_HIP(hipGetLastError());
   return 0;
 }

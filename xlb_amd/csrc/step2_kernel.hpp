@@ -22,6 +22,15 @@
 #ifndef XLB_STEP2_ALIGN
 #define XLB_STEP2_ALIGN 256
 #endif
+#ifndef XLB_PIN_CLEAN
+#define XLB_PIN_CLEAN true
+#endif
+#ifndef XLB_PIN_BC
+#define XLB_PIN_BC true
+#endif
+#ifndef XLB_STEP2_PLAIN_GMAX
+#define XLB_STEP2_PLAIN_GMAX 1  // pair-group width of the kernel without boundary conditions
+#endif
 #ifndef XLB_STEP2_CLEAN_GMAX
 #define XLB_STEP2_CLEAN_GMAX 3  // pair-group width of the BC-free body inside the BC kernel (1 makes hipcc park the pairs in scratch there)
 #endif
@@ -136,7 +145,7 @@ __device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_
 
 // The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
 // run either boundary-condition form of the body in the same allocation).
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX>
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN>
 __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsigned* ldsmeta, T* bcval) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
@@ -172,7 +181,10 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
   const int n_seg = a.x_segments > 0 ? a.x_segments : 1;
   int x_lo, x_hi;
   step2_seg_range(a.x_begin, a.x_count, n_seg, a.x_cap, (int)seg, x_lo, x_hi);
-  const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
+  // The tiling may be shifted by (tile_oy, tile_oz) cells, periodically: with walls on the y / z faces a shift of half a
+  // tile puts BOTH walls of an axis into the one tile row that wraps around the box, halving the number of hull tiles
+  // (the expensive ones: every wave of a z-face tile is a boundary wave) — 71 instead of 140 at 512^2.
+  const int ty0 = (int)(tile / tiles_z) * TY + a.tile_oy, tz0 = (int)(tile % tiles_z) * TZ + a.tile_oz;
   const int t = threadIdx.x;
   const int nx = a.nx, ny = a.ny, nz = a.nz;
   const size_t plane_cells = (size_t)ny * nz;
@@ -211,7 +223,9 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
   const bool act_b = t < G::NB;
   const int tb = act_b ? t : t % G::NB;
   const int jb = tb / TZ, kb = tb % TZ;
-  const int yb = ty0 + jb, zb = tz0 + kb;
+  int yb = ty0 + jb, zb = tz0 + kb;
+  yb = yb >= ny ? yb - ny : yb;
+  zb = zb >= nz ? zb - nz : zb;
   const unsigned cell_b = (unsigned)yb * (unsigned)nz + (unsigned)zb;
   const int ctr_b = (jb + 1) * EZ + (kb + 1);  // my cell inside a grown-tile slot
 
@@ -231,7 +245,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
   auto finish = [&](T(&f)[Q], bool fullway) __attribute__((always_inline)) {
     if (!fullway) {
       if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4)
-        collide_bgk_packed<L, GMAX>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp); GMAX: measured best 3 / 1 (with / without BCs)
+        collide_bgk_packed<L, GMAX, PIN>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp); GMAX: measured best 3 / 1 (with / without BCs)
       else
         collide<L, T, COLL>(f, a.omega, a.extra);
     } else {
@@ -508,18 +522,18 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   if constexpr (HASBC != 0) {
     if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
-      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX>(a, lds, ldsmeta, bcval);
+      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN>(a, lds, ldsmeta, bcval);
       return;
     }
   }
-  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : 1)>(a, lds, ldsmeta, bcval);
+  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false)>(a, lds, ldsmeta, bcval);
 }
 
 // clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel
 // visits them — carries a boundary condition.  Same block -> (tile, segment) mapping as k_step2; one block per item.
 template <int TY, int TZ, bool SLAB>
 __global__ void k_step2_clean(const uint32_t* meta /*advanced to interior plane 0 when SLAB*/, const uint32_t* tile_order, int xcd_swizzle, int x_segments,
-                              int x_cap, int x_begin, int x_count, int nx, int ny, int nz, uint8_t* clean) {
+                              int x_cap, int x_begin, int x_count, int nx, int ny, int nz, int tile_oy, int tile_oz, uint8_t* clean) {
   constexpr int EY = TY + 2, EZ = TZ + 2, NE = EY * EZ;
   const unsigned tiles_z = (unsigned)nz / TZ, tiles_y = (unsigned)ny / TY, n_tiles = tiles_y * tiles_z;
   const unsigned seg = blockIdx.x / n_tiles, slot_in_seg = blockIdx.x % n_tiles;
@@ -533,7 +547,7 @@ __global__ void k_step2_clean(const uint32_t* meta /*advanced to interior plane 
   const int n_seg = x_segments > 0 ? x_segments : 1;
   int x_lo, x_hi;
   step2_seg_range(x_begin, x_count, n_seg, x_cap, (int)seg, x_lo, x_hi);
-  const int ty0 = (int)(tile / tiles_z) * TY, tz0 = (int)(tile % tiles_z) * TZ;
+  const int ty0 = (int)(tile / tiles_z) * TY + tile_oy, tz0 = (int)(tile % tiles_z) * TZ + tile_oz;
   const ptrdiff_t pc = (ptrdiff_t)ny * nz;
   int dirty = 0;
   for (int p = x_lo - 1; p <= x_hi + 1; ++p) {

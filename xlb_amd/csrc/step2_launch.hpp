@@ -31,6 +31,8 @@ static int launch2(const StepLaunch& p) {
   a.clean = (HASBC != 0) ? p.clean : nullptr;
   a.x_segments = step2_eff_segments(p);
   a.x_cap = step2_eff_cap(p);
+  a.tile_oy = p.tile_oy;
+  a.tile_oz = p.tile_oz;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const float*>(p.tab_values);
   a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)

@@ -39,6 +39,7 @@ struct StepArgs {
   const uint32_t* tile_order;  // two-step kernel only: block -> tile, or nullptr
   int x_segments;              // two-step kernel only: x cuts per tile column (>= 1)
   int x_cap;                   // two-step kernel only: > 0: the first and last segment are x_cap planes thin (>= 3 segments)
+  int tile_oy, tile_oz;        // two-step kernel only: origin shift of the tiling (periodic), see step2_kernel.hpp
   const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
   const uint8_t* clean;   // two-step kernel only: per block, 1 = no boundary cell in its work item (k_step2_clean), or nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms

@@ -16,6 +16,7 @@ struct StepLaunch {
   const uint8_t* clean;        // two-step kernel only: per-block "no boundary cells" flags for THIS launch geometry, or nullptr
   int x_segments;              // two-step kernel only
   int x_cap;                   // two-step kernel only: thin first / last segment (planes), 0 = uniform cuts
+  int tile_oy, tile_oz;        // two-step kernel only: periodic origin shift of the tiling (0 .. tile - 1)
   int tile_ty, tile_tz;        // two-step kernel only: tile of the (y, z) plane a block owns
   const uint8_t* tab_kind;
   const void* tab_values;  // compute dtype [256][27]
@@ -73,6 +74,7 @@ int launch_typed(const StepLaunch& p) {
   a.tile_order = nullptr;
   a.x_segments = 1;
   a.x_cap = 0;
+  a.tile_oy = a.tile_oz = 0;
   a.bc_kind = p.tab_kind;
   a.bc_values = static_cast<const T*>(p.tab_values);
   a.prof_keys = p.prof_keys;
