@@ -153,6 +153,7 @@ class Context:
         check(load().xlbhip_create(int(device), C.byref(self._h)))
         self.device = int(device)
         self.rank, self.n_ranks = 0, 1
+        self._flushers = []  # weak references to objects with deferred device work (steppers pairing reference-style calls)
 
     @property
     def handle(self):
@@ -160,7 +161,18 @@ class Context:
             raise HipBackendError("context already destroyed")
         return self._h
 
+    def flush_deferred(self):
+        """Enqueue whatever work operators have deferred (IncompressibleNavierStokesStepper pairs reference-style calls)."""
+        alive = []
+        for ref in self._flushers:
+            obj = ref()
+            if obj is not None:
+                obj._flush_deferred()
+                alive.append(ref)
+        self._flushers = alive
+
     def sync(self):
+        self.flush_deferred()
         check(load().xlbhip_sync(self.handle))
 
     def set_option(self, key, value):
@@ -271,6 +283,8 @@ class Field:
         self.halo = int(halo)
         s3 = (1,) + self.grid_shape if len(self.grid_shape) == 2 else self.grid_shape
         self._s3 = s3
+        self._hook = None     # called before any access through .handle (deferred work that involves this field)
+        self._pinned = False  # exported through DLPack / CUDA array interface: its device memory must never be swapped
         self._h = _p()
         check(load().xlbhip_field_create(ctx.handle, self.cardinality, s3[0], s3[1], s3[2], self.dtype_code, self.halo,
                                          float(fill_value or 0.0), C.byref(self._h)))
@@ -286,6 +300,9 @@ class Field:
 
     @property
     def handle(self):
+        if self._hook is not None:
+            hook, self._hook = self._hook, None
+            hook(self)
         if not self._h:
             raise HipBackendError("field already destroyed")
         return self._h
@@ -318,6 +335,7 @@ class Field:
         """CUDA Array Interface v3 (PyTorch-ROCm, CuPy-ROCm and Numba consume it): ``torch.as_tensor(field, device="cuda")``
         aliases the field's memory.  Work enqueued on the backend's stream is finished first."""
         ptr, shape, strides, item = self._device_view()
+        self._pinned = True
         self.ctx.sync()
         return {"shape": shape, "strides": tuple(s * item for s in strides), "typestr": self.dtype.str, "data": (ptr, False), "version": 3}
 
@@ -328,6 +346,7 @@ class Field:
         """DLPack capsule of the same strided view (``torch.from_dlpack(field)``).  The consumer's stream is not known to
         this backend, so the backend's own stream is drained before the capsule is handed out."""
         ptr, shape, strides, item = self._device_view()
+        self._pinned = True
         self.ctx.sync()
         return _dlpack_capsule(self, ptr, shape, strides, self.dtype, self.ctx.device)
 
@@ -386,13 +405,22 @@ class Field:
                 "plane_stride": ps.value, "device_ptr": ptr.value}
 
     def free(self):
+        if self._hook is not None:
+            hook, self._hook = self._hook, None
+            try:
+                hook(self)
+            except Exception:
+                pass
         if self._h:
             load().xlbhip_field_destroy(self._h)
             self._h = _p()
 
     def __del__(self):
         try:
-            self.free()
+            self._hook = None
+            if self._h:
+                load().xlbhip_field_destroy(self._h)
+                self._h = _p()
         except Exception:
             pass
 

@@ -990,6 +990,12 @@ struct xlbhip_stepper {
   // two-step kernel: per launch geometry (x_begin, x_count, segments, tile order?, swizzle) the per-block "no boundary
   // cell" flags; dropped whenever the meta words are rebuilt
   std::map<std::array<int, 5>, uint8_t*> clean_cache;
+  // the masks (address + contents version) the meta words were built from: xlbhip_step2 called per pair (the Python
+  // stepper pairing reference-style calls) must not rebuild them every time
+  const xlbhip_field* meta_bc = nullptr;
+  const xlbhip_field* meta_miss = nullptr;
+  uint64_t meta_bc_version = 0, meta_miss_version = 0;
+  unsigned long long meta_opts = 0;
   bool forced = false;
   double force[3] = {0, 0, 0};
   double smag_cs = 0.17;
@@ -1338,6 +1344,7 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     s->meta = nullptr;
     XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
     s->meta_cells = cells;
+    s->meta_bc = nullptr;  // (contents gone: rebuild below)
   }
   const int tys = bcm->ny / fuse2_tile_ty(c), tzs = bcm->nz / fuse2_tile_tz(c);
   const bool shifted = opt(c, "fuse2_shift", 1) != 0;
@@ -1402,6 +1409,15 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     s->order_ty = tys;
     s->order_tz = tzs;
   }
+  const unsigned long long opts_key = (unsigned long long)opt(c, "fuse2_shift", 1) | ((unsigned long long)opt(c, "external_halo", 0) << 1);
+  if (s->meta_bc == bcm && s->meta_miss == miss && s->meta_bc_version == bcm->version && s->meta_miss_version == (miss ? miss->version : 0) &&
+      s->meta_opts == opts_key)
+    return 0;  // meta words, tile order and clean flags are those of these very masks
+  s->meta_bc = bcm;
+  s->meta_miss = miss;
+  s->meta_bc_version = bcm->version;
+  s->meta_miss_version = miss ? miss->version : 0;
+  s->meta_opts = opts_key;
   drop_clean_cache(s);  // (stream-ordered: the flags' last readers were enqueued before this point and hipFree synchronises)
   hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, c->stream, static_cast<const uint8_t*>(bcm->data),
                      miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,

@@ -13,7 +13,17 @@ target) / :427-476 (fused Warp kernel, the structural model).
 ``stepper.run(f_0, f_1, bc_mask, missing_mask, omega, n_steps)`` runs the same loop natively
 (no per-step Python dispatch, which costs tens of microseconds per call in the reference's
 ``Operator.__call__``).
-"""
+
+**Pairing of reference-style calls.**  The fast kernel advances TWO steps per pass (csrc/step2_kernel.hpp).  So that an
+unmodified XLB driver — the loop above, every example of the reference (mlups_3d.py:237-238) — gets it too, a call on
+fields the two-step kernel supports is DEFERRED: nothing is enqueued; when the next call arrives with the two
+population fields swapped (same masks, same omega) both steps run as one fused pass, otherwise — any other use of either
+field, ``ctx.sync()``, a different call — the deferred step runs first as a single step.  The results are bit-identical
+to single steps.  After a fused pair the field that received step t+1 in the reference's protocol holds it only virtually
+(the fused pass writes f(t+2) next to f(t), and the two field objects exchange their device buffers): if it is read
+before the next call overwrites it, it is materialised through a temporary third field.  Fields exported through DLPack /
+``__cuda_array_interface__`` are never deferred (their memory must stay put); ``backend_config={"lazy_pairs": False}``
+switches the mechanism off."""
 
 import numpy as np
 
@@ -32,6 +42,17 @@ from ..stream import Stream
 from .stepper import Stepper
 
 
+class _Materialise:
+    """Hook of a field that holds f(t+1) only virtually after a fused pair (its buffer holds f(t)): see _lazy_pair."""
+
+    def __init__(self, stepper, bcm, miss, omega, t):
+        self.args = (stepper, bcm, miss, omega, t)
+
+    def __call__(self, field):
+        stepper, bcm, miss, omega, t = self.args
+        stepper._materialise(field, bcm, miss, omega, t)
+
+
 class IncompressibleNavierStokesStepper(Stepper):
     def __init__(self, grid, boundary_conditions=[], collision_type="BGK", streaming_scheme="pull",
                  forcing_scheme="exact_difference", force_vector=None, backend_config={}):
@@ -47,6 +68,8 @@ class IncompressibleNavierStokesStepper(Stepper):
         self.forcing_scheme = forcing_scheme
         self.force_vector = force_vector
         self._native = None
+        self._deferred = None   # (f_src, f_dst, bc_mask, missing_mask, omega, timestep): a step not enqueued yet
+        self._n_fused_pairs = self._n_materialised = 0  # statistics of the pairing (tests, diagnostics)
         super().__init__(grid, boundary_conditions)
         vs, pp, be = self.velocity_set, self.precision_policy, self.compute_backend
         if collision_type == "BGK":
@@ -116,11 +139,74 @@ class IncompressibleNavierStokesStepper(Stepper):
 
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_0, f_1, bc_mask, missing_mask, omega, timestep):
-        self._native_stepper().step(f_0, f_1, bc_mask, missing_mask, omega, timestep)
+        if not self._lazy_pair(f_0, f_1, bc_mask, missing_mask, omega, timestep):
+            self._native_stepper().step(f_0, f_1, bc_mask, missing_mask, omega, timestep)
         return f_0, f_1
+
+    # -- pairing of reference-style calls (module docstring) ------------------------------------------------------
+    def _lazy_eligible(self, f_0, f_1, bc_mask, missing_mask):
+        if not self.backend_config.get("lazy_pairs", True) or f_0.halo != 0 or f_0._pinned or f_1._pinned:
+            return False
+        # (asked every time: the answer follows the backend options — fuse2, ... — and the masks' contents; host logic only)
+        return self._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+
+    def _flush_deferred(self, *_):
+        """Enqueue the deferred step as a single step (some other use of its fields came first)."""
+        d, self._deferred = self._deferred, None
+        if d is None:
+            return
+        f_src, f_dst, bcm, miss, omega, t = d
+        f_src._hook = f_dst._hook = None
+        self._native_stepper().step(f_src, f_dst, bcm, miss, omega, t)
+
+    def _materialise(self, field, bcm, miss, omega, t):
+        """`field` should hold f(t+1) but its buffer holds f(t) (a fused pair passed it by): one single step through a
+        temporary field, whose buffer the field then adopts."""
+        field._hook = None
+        self._n_materialised += 1
+        tmp = self.grid.create_field(cardinality=self.velocity_set.q, dtype=self.precision_policy.store_precision)
+        self._native_stepper().step(field, tmp, bcm, miss, omega, t)
+        field._h, tmp._h = tmp._h, field._h
+        tmp.free()
+
+    def _lazy_pair(self, f_0, f_1, bc_mask, missing_mask, omega, timestep):
+        """True when this call was absorbed (deferred, or executed as the second half of a fused pair)."""
+        if isinstance(f_1._hook, _Materialise):
+            f_1._hook = None  # a virtual f(t+1) in the destination is about to be overwritten: nothing to materialise
+        d = self._deferred
+        if d is not None:
+            f_src, f_dst, bcm, miss, om, t = d
+            if f_0 is f_dst and f_1 is f_src and bc_mask is bcm and missing_mask is miss and float(omega) == om and not (f_0._pinned or f_1._pinned):
+                # the caller swapped the fields: steps t and t + 1 in one pass, f(t) in f_src's buffer -> f(t+2) in f_dst's
+                self._deferred = None
+                f_src._hook = f_dst._hook = None
+                if not self._native_stepper().step2_eligible(f_src, f_dst, bcm, miss):  # (an option changed in between)
+                    self._native_stepper().step(f_src, f_dst, bcm, miss, om, t)
+                    return False
+                self._native_stepper().step2(f_src, f_dst, bcm, miss, om, t)
+                self._n_fused_pairs += 1
+                # the reference's protocol leaves f(t+2) in THIS call's f_1 (= f_src) and f(t+1) in its f_0 (= f_dst):
+                # exchange the buffers; f_dst now holds f(t) instead of f(t+1) until someone looks
+                f_src._h, f_dst._h = f_dst._h, f_src._h
+                f_dst._hook = _Materialise(self, bcm, miss, om, t)
+                return True
+            self._flush_deferred()
+        if not self._lazy_eligible(f_0, f_1, bc_mask, missing_mask):
+            return False
+        # defer: whoever touches either field first (or ctx.sync()) makes it run
+        if f_0._hook is not None:  # the source itself is virtual (read it properly first)
+            f_0.handle
+        self._deferred = (f_0, f_1, bc_mask, missing_mask, float(omega), timestep)
+        f_0._hook = f_1._hook = self._flush_deferred
+        import weakref
+
+        if not any(r() is self for r in self._ctx._flushers):
+            self._ctx._flushers.append(weakref.ref(self))
+        return True
 
     def run(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """``n_steps`` x (step, swap) in native code; returns (f_current, f_other)."""
+        self._flush_deferred()
         if f_0.halo > 0 and self._ctx.get_option("external_halo"):
             return self._run_host_staged(f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep)
         in_b = self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
@@ -128,6 +214,7 @@ class IncompressibleNavierStokesStepper(Stepper):
 
     def run_timed(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """As :meth:`run`; also returns the device time in ms measured with HIP events."""
+        self._flush_deferred()
         if f_0.halo > 0 and self._ctx.get_option("external_halo"):
             import time
 
