@@ -7,4 +7,3 @@ bash tools/profile.sh r02_d3q27_kbc_384_fp64fp32_fast --workload periodic --size
 bash tools/profile.sh r02_d3q27_bgk_384_two_step --workload periodic --size 384 --lattice D3Q27 --steps 100 > gpurun_out/prof_d.log 2>&1; echo "d3q27 rc=$?"
 bash tools/profile.sh r02_cavity_fullway_512 --workload cavity_fullway > gpurun_out/prof_e.log 2>&1; echo "fullway rc=$?"
 bash tools/profile.sh r02_periodic_512 --workload periodic > gpurun_out/prof_f.log 2>&1; echo "p512 rc=$?"
-python tools/design_table.py > gpurun_out/design_table.md 2> gpurun_out/design_table.err; cat gpurun_out/design_table.md
