@@ -245,12 +245,13 @@ def cpu_baseline(args):
 
 
 def kernel_source_hash():
-    """Hash of the kernel sources the library was built from: PMC traffic figures in profiles/traffic.json are only
-    quoted for the build they were measured on."""
+    """Hash of the sources that decide what the step kernels do and how they are launched (the kernels, their launchers
+    and the scheduling logic of api.hip): PMC traffic figures in profiles/traffic.json are only quoted for the build
+    they were measured on.  (ops_kernels.hpp — whole-field operators, maskers — and comm.cpp are not part of it.)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "xlb_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hpp", ".hip", ".cpp")):
+        if name.endswith((".hpp", ".hip", ".cpp")) and name not in ("ops_kernels.hpp", "comm.cpp", "comm.hpp", "common.hpp"):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]

@@ -99,7 +99,15 @@ int xlbhip_destroy(xlbhip_ctx* ctx);
 int xlbhip_sync(xlbhip_ctx* ctx);                 /* wp.synchronize(), mlups_3d.py:230 */
 const char* xlbhip_last_error(void);
 int xlbhip_device_info(xlbhip_ctx* ctx, char* name, int name_len, int* compute_units, uint64_t* hbm_bytes);
-/* tuning knobs (kernel variant selection etc.); unknown keys are an error */
+/* tuning knobs (kernel variant selection etc.); unknown keys are an error.  The ones with semantics:
+ *   exact_math      0 (default): fp64-compute D3Q27 KBC runs the tolerance-graded fast collision (rounding-level
+ *                   differences from the bit-exact build, <= 4e-16 measured; north-star tolerance 1e-6); 1: bit-exact builds only
+ *   fuse2           xlbhip_run* pair their steps through the two-step kernel: 0 never, 1 where eligible and the work
+ *                   items fill the chip, 2 wherever eligible
+ *   external_halo   1: the caller refills the ghost planes before every xlbhip_step / xlbhip_step2 (host-staged transports)
+ *   overlap         0: no overlap of the halo exchange with the interior launch (measurement)
+ * Pure tuning (results identical): vec, nt_store, nt_load, plane_pad_bytes (at field creation), block_threads, block_tz,
+ * xcd_swizzle, fuse2_xseg / _lpt / _xcd / _clean / _xcap / _shift / _tile / _cus (csrc/api.hip: xlbhip_create). */
 int xlbhip_set_option(xlbhip_ctx* ctx, const char* key, int64_t value);
 int xlbhip_get_option(xlbhip_ctx* ctx, const char* key, int64_t* value);
 

@@ -52,6 +52,8 @@ static Dims dims(const xlbhip_field* f) { return Dims{f->nx, f->ny, f->nz}; }
 static bool same_grid(const xlbhip_field* a, const xlbhip_field* b) { return a->nx == b->nx && a->ny == b->ny && a->nz == b->nz; }
 static bool is_float(int dt) { return dt == XLBHIP_F64 || dt == XLBHIP_F32 || dt == XLBHIP_F16; }
 static unsigned blocks_for(size_t n, int threads = 256) { return (unsigned)((n + threads - 1) / threads); }
+// for the grid-stride kernels (k_copy, k_fill): HIP refuses launches of 2^32 threads or more
+static unsigned blocks_capped(size_t n, int threads = 256) { return (unsigned)std::min<size_t>((n + threads - 1) / threads, (size_t)1 << 23); }
 
 template <class F>
 static int by_lattice(int lattice, F&& f) {
@@ -283,11 +285,11 @@ int xlbhip_field_fill(xlbhip_field* f, double v) {
   }
   const size_t n = f->planes * f->plane_stride;
   switch (f->dtype) {
-    case XLBHIP_F64: hipLaunchKernelGGL(k_fill<double>, blocks_for(n), 256, 0, st, (double*)f->data, n, v); break;
-    case XLBHIP_F32: hipLaunchKernelGGL(k_fill<float>, blocks_for(n), 256, 0, st, (float*)f->data, n, (float)v); break;
-    case XLBHIP_F16: hipLaunchKernelGGL(k_fill<_Float16>, blocks_for(n), 256, 0, st, (_Float16*)f->data, n, (_Float16)v); break;
-    case XLBHIP_U8: hipLaunchKernelGGL(k_fill<uint8_t>, blocks_for(n), 256, 0, st, (uint8_t*)f->data, n, (uint8_t)v); break;
-    case XLBHIP_BOOL: hipLaunchKernelGGL(k_fill<uint8_t>, blocks_for(n), 256, 0, st, (uint8_t*)f->data, n, (uint8_t)(v != 0.0)); break;
+    case XLBHIP_F64: hipLaunchKernelGGL(k_fill<double>, blocks_capped(n), 256, 0, st, (double*)f->data, n, v); break;
+    case XLBHIP_F32: hipLaunchKernelGGL(k_fill<float>, blocks_capped(n), 256, 0, st, (float*)f->data, n, (float)v); break;
+    case XLBHIP_F16: hipLaunchKernelGGL(k_fill<_Float16>, blocks_capped(n), 256, 0, st, (_Float16*)f->data, n, (_Float16)v); break;
+    case XLBHIP_U8: hipLaunchKernelGGL(k_fill<uint8_t>, blocks_capped(n), 256, 0, st, (uint8_t*)f->data, n, (uint8_t)v); break;
+    case XLBHIP_BOOL: hipLaunchKernelGGL(k_fill<uint8_t>, blocks_capped(n), 256, 0, st, (uint8_t*)f->data, n, (uint8_t)(v != 0.0)); break;
     default: XLB_FAIL("cannot fill dtype %d with a non-zero value", f->dtype);
   }
   XLB_HIP(hipGetLastError());
@@ -314,10 +316,10 @@ int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int byt
   hipStream_t st = dst->ctx->stream;
   if (bytes_per_lane == 4) {
     const size_t n = bytes / 4;
-    hipLaunchKernelGGL(k_copy<uint32_t>, blocks_for(n), 256, 0, st, (const uint32_t*)src->data, (uint32_t*)dst->data, n);
+    hipLaunchKernelGGL(k_copy<uint32_t>, blocks_capped(n), 256, 0, st, (const uint32_t*)src->data, (uint32_t*)dst->data, n);
   } else {
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(k_copy<u32x4>, blocks_for(n), 256, 0, st, (const u32x4*)src->data, (u32x4*)dst->data, n);
+    hipLaunchKernelGGL(k_copy<u32x4>, blocks_capped(n), 256, 0, st, (const u32x4*)src->data, (u32x4*)dst->data, n);
   }
   XLB_HIP(hipGetLastError());
   return 0;
@@ -889,7 +891,7 @@ extern "C" int xlbhip_mesh_mask(xlbhip_ctx* c, int lattice, int method, int bc_i
   unsigned* tbuf = nullptr;  // closest ray parameter per (link, voxel), +inf = none
   if (dist || method == XLBHIP_MESH_WINDING) {
     XLB_HIP(scratch.alloc(&tbuf, (size_t)q * cells * sizeof(unsigned)));
-    hipLaunchKernelGGL(k_fill<unsigned>, blocks_for((size_t)q * cells), 256, 0, st, tbuf, (size_t)q * cells, T_NONE);
+    hipLaunchKernelGGL(k_fill<unsigned>, blocks_capped((size_t)q * cells), 256, 0, st, tbuf, (size_t)q * cells, T_NONE);
   }
   uint8_t* bcp = static_cast<uint8_t*>(bcm->data);
   uint32_t* mp = static_cast<uint32_t*>(miss->data);

@@ -507,8 +507,9 @@ __global__ void k_unpack_missing(const uint32_t* bits, uint8_t* bytes, int q, Di
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <class V>
 __global__ void k_copy(const V* __restrict__ src, V* __restrict__ dst, size_t n) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) __builtin_nontemporal_store(src[i], dst + i);
+  // grid-stride: HIP refuses launches of 2^32 threads or more, an 81.6 GB field (4096 x 512 x 512, D3Q19) has 5.1e9 16-byte words
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(src[i], dst + i);
 }
 
 // ---- MeshMaskerAABB (boundary_masker/aabb.py:38-100, mesh_boundary_masker.py:62-181): surface voxelisation of a
@@ -970,8 +971,7 @@ __global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* 
 
 template <class E>
 __global__ void k_fill(E* p, size_t n, E v) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;  // grid-stride (see k_copy)
 }
 
 }  // namespace xlb

@@ -481,6 +481,10 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
   };
 
   // Plane x_lo + p is plane q = p + 1 of the ring (p = -1: the periodic image / ghost plane below the segment).
+  // (fix[] deliberately has NO initialiser, not even in the prologue: a second writer of a register that an inline-asm load
+  // targets makes hipcc insert a copy right behind the asm statement — before the hand-placed wait, i.e. of stale data.  Lanes
+  // that loaded nothing never select their fix[] value.  tests/test_capi_symbols.py checks the compiled code: no scratch, and
+  // >= 19 stores between the fix-up loads and the counted wait.)
   S raw[Q], fix[Q];
   unsigned w_raw = 0, mall_raw = 0;  // meta word / wave union of the plane held in raw
   // prologue: planes -1, 0, 1 straight into the ring (synchronous), then the pulls of plane 2 go in flight.
