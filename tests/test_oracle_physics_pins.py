@@ -5,6 +5,8 @@ independent of this repository's oracle / kernels agreeing with each other:
   * Taylor-Green vortex in a periodic D2Q9 box: the velocity amplitude decays as exp(-2 nu k^2 t) with the BGK viscosity
     nu = (1 / omega - 1 / 2) / 3  (bgk.py:27-32 + quadratic_equilibrium.py:23-30 + stream.py:29-62 composed as
     nse_stepper.py:237-282);
+  * the same vortex under KBC (D2Q9, D3Q27): the shear part is relaxed with 2 beta = omega, so the decay rate — hence the
+    hard-coded shear tables of kbc.py:120-143 / :163-172 — is pinned too;
   * Couette flow between two halfway bounce-back walls: the steady profile is the straight line through walls that sit HALF A
     CELL outside the boundary nodes, for every relaxation rate.  An independently written textbook step (own lattice order,
     own formulas) reproduces it to rounding, and the oracle's / the HIP backend's HalfwayBounceBackBC step (moving wall
@@ -92,6 +94,40 @@ def test_taylor_green_decay_gives_the_bgk_viscosity(omega):
     assert abs(nu / ((1.0 / omega - 0.5) / 3.0) - 1.0) < 0.01
 
 
+def taylor_green_3d(n, nz, u0, lat, policy):
+    """the same 2-D vortex, uniform along z, in a D3Q27 box"""
+    T = orc.compute_dtype(policy)
+    k = 2.0 * np.pi / n
+    x, y, z = np.meshgrid(np.arange(n), np.arange(n), np.arange(nz), indexing="ij")
+    ux = -u0 * np.cos(k * x) * np.sin(k * y)
+    uy = u0 * np.sin(k * x) * np.cos(k * y)
+    rho = 1.0 - 0.75 * u0 * u0 * (np.cos(2 * k * x) + np.cos(2 * k * y))
+    f = orc.equilibrium(rho[None].astype(T), np.stack([ux, uy, np.zeros_like(ux)]).astype(T), lat, T)
+    return f.astype(orc.store_dtype(policy)), k
+
+
+@pytest.mark.parametrize("lattice,omega", [("D2Q9", 1.2), ("D2Q9", 1.8), ("D3Q27", 1.5)])
+def test_taylor_green_decay_with_kbc_gives_the_same_viscosity(lattice, omega):
+    """KBC relaxes the shear part of the non-equilibrium with 2 beta = omega whatever the entropic stabiliser gamma does to
+    the rest (kbc.py:58-94: f - beta (2 ds + gamma dh)), so the vortex must decay with the BGK viscosity.  A wrong entry in
+    the hard-coded shear tables (kbc.py:120-143, :163-172) or a wrong 1/4, 1/6 factor changes the decay rate."""
+    lat = orc.Lattice(lattice)
+    policy, n = "FP64FP64", 24
+    if lattice == "D2Q9":
+        f, k = taylor_green_init(n, 0.01, lat, policy)
+        shape = (n, n)
+    else:
+        f, k = taylor_green_3d(n, 3, 0.01, lat, policy)
+        shape = (n, n, 3)
+    bm, mm = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+    f = orc.run(f, bm, mm, [], omega, lat, 60, policy, "KBC")
+    a1 = amplitude(f, lat)
+    f = orc.run(f, bm, mm, [], omega, lat, 120, policy, "KBC")
+    a2 = amplitude(f, lat)
+    nu = np.log(a1 / a2) / (2.0 * k * k * 120)
+    assert abs(nu / ((1.0 / omega - 0.5) / 3.0) - 1.0) < 0.02
+
+
 def test_textbook_halfway_bounce_back_gives_the_exact_couette_profile():
     """Theory: between two halfway bounce-back walls the steady Couette profile is linear through walls that sit HALF A CELL
     outside the boundary nodes, for any relaxation rate — the textbook step reproduces it to rounding."""
@@ -141,6 +177,29 @@ def test_taylor_green_decay_on_the_hip_backend(omega):
     a2 = amplitude(f_0.numpy(), lat)
     nu = np.log(a1 / a2) / (2.0 * k * k * 200)
     assert abs(nu / ((1.0 / omega - 0.5) / 3.0) - 1.0) < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", ["FP64FP64", "FP64FP32"])
+def test_taylor_green_decay_with_kbc_on_the_hip_backend(policy):
+    """D3Q27 KBC through the step kernel — the default fast fp64 collision included — decays with the BGK viscosity."""
+    from xlb_amd.grid import grid_factory
+    from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
+    from _util import init_hip
+
+    vs, pp = init_hip("D3Q27", policy)
+    lat = orc.Lattice("D3Q27")
+    n, omega = 24, 1.5
+    f_np, k = taylor_green_3d(n, 4, 0.01, lat, policy)
+    stepper = IncompressibleNavierStokesStepper(grid=grid_factory((n, n, 4)), boundary_conditions=[], collision_type="KBC")
+    f_0, f_1, bm, mm = stepper.prepare_fields()
+    f_0.assign(f_np)
+    f_0, f_1 = stepper.run(f_0, f_1, bm, mm, omega, 60)
+    a1 = amplitude(f_0.numpy(), lat)
+    f_0, f_1 = stepper.run(f_0, f_1, bm, mm, omega, 120)
+    a2 = amplitude(f_0.numpy(), lat)
+    nu = np.log(a1 / a2) / (2.0 * k * k * 120)
+    assert abs(nu / ((1.0 / omega - 0.5) / 3.0) - 1.0) < 0.02
 
 
 @pytest.mark.gpu
