@@ -102,6 +102,8 @@ int xlbhip_device_info(xlbhip_ctx* ctx, char* name, int name_len, int* compute_u
 /* tuning knobs (kernel variant selection etc.); unknown keys are an error.  The ones with semantics:
  *   exact_math      0 (default): fp64-compute D3Q27 KBC runs the tolerance-graded fast collision (rounding-level
  *                   differences from the bit-exact build, <= 4e-16 measured; north-star tolerance 1e-6); 1: bit-exact builds only
+ *   fast_bgk        1 (default 0): the two-step kernel uses the tolerance-graded fast BGK body (rounding-level differences,
+ *                   <= 3e-7 measured over 10 steps in fp32; +2-4 %); ignored with exact_math=1
  *   fuse2           xlbhip_run* pair their steps through the two-step kernel: 0 never, 1 where eligible and the work
  *                   items fill the chip, 2 wherever eligible
  *   external_halo   1: the caller refills the ghost planes before every xlbhip_step / xlbhip_step2 (host-staged transports)

@@ -72,3 +72,35 @@ def test_fast_kbc_cavity_with_walls():
     o_bm, o_mm = orc.build_masks(shape, lat, obcs)
     exp = orc.run(orc.initialize_eq(shape, lat, "FP64FP32"), o_bm, o_mm, obcs, omega, lat, steps, "FP64FP32", "KBC")
     assert np.abs(f_0.numpy().astype(np.float64) - exp.astype(np.float64)).max() <= TOL
+
+
+@pytest.mark.parametrize("lattice,shape", [("D3Q19", (6, 16, 64)), ("D3Q27", (5, 8, 64))])
+def test_fast_bgk_body_of_the_two_step_kernel_is_within_tolerance(lattice, shape):
+    """Opt-in `fast_bgk=1` (cell.hpp: bgk_fast — one reciprocal, FMAs, shared E / O per pair) in the two-step kernel: rounding-
+    level differences from the oracle; the default stays bit-exact."""
+    vs, pp = init_hip(lattice)
+    ctx = get_context()
+    lat = orc.Lattice(lattice)
+    f_np = orc.perturbed_init(shape, lat, seed=9, amp_rho=0.02, amp_u=0.03)
+    bm, mm = orc.build_masks(shape, lat, [])
+    steps = 10
+    exp = orc.run(f_np, bm, mm, [], 1.6, lat, steps)
+    outs = {}
+    try:
+        ctx.set_option("fuse2", 2)
+        for fast in (0, 1):
+            ctx.set_option("fast_bgk", fast)
+            grid = grid_factory(shape)
+            stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[])
+            f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+            assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+            f_0.assign(f_np)
+            f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.6, steps)
+            outs[fast] = f_0.numpy()
+    finally:
+        ctx.set_option("fast_bgk", 0)
+        ctx.set_option("fuse2", 1)
+    assert np.array_equal(outs[0], exp)
+    err = float(np.abs(outs[1].astype(np.float64) - exp.astype(np.float64)).max())
+    print(f"fast BGK two-step {lattice}: max |f - oracle| = {err:.3e}")
+    assert 0.0 < err <= TOL

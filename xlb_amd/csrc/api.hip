@@ -161,6 +161,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_clean"] = 1;      // two-step kernel with BCs: work items without boundary cells run the BC-free body (same launch)
   c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
+  c->opts["fast_bgk"] = 0;         // two-step kernel: 1 = tolerance-graded fast BGK body (rounding-level differences; +2-4 %)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   *out = c;
@@ -1118,6 +1119,7 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.block_tz = (int)opt(c, "block_tz", 0);
   p.xcd_swizzle = (int)opt(c, "xcd_swizzle", 0);
   p.fast_math = opt(c, "exact_math", 0) ? 0 : 1;
+  p.fast_bgk = (opt(c, "fast_bgk", 0) && !opt(c, "exact_math", 0)) ? 1 : 0;
   p.stream = c->stream;
   p.x_begin = 0;
   p.x_count = src->nx;

@@ -736,6 +736,60 @@ __device__ __forceinline__ void bgk_packed_pairs(float (&f)[L::Q], float rho, co
   });
 }
 
+// ---- BGK, tolerance-graded fast form (the two-step kernel is bound by VALU issue, not by HBM) ------------------------------
+// Same relaxation as bgk() (bgk.py:27-32 with quadratic_equilibrium.py:23-30), evaluated for speed: one reciprocal for the
+// three u = j / rho, FMAs, and the (l, opp l) pairs share E = 1 - usqr + 4.5 d^2 and O = 3 d (d = c_l . u):
+//   f'_l = (1 - omega) f_l + omega rho w (E + O),   f'_o = (1 - omega) f_o + omega rho w (E - O)
+// ~150 VALU instructions per cell instead of ~230.  Differs from the bit-exact form by rounding only (a few ulp per step;
+// tests/test_gpu_fastmath.py measures it against the oracle); `exact_math=1` selects the bit-exact form.
+template <class L>
+__device__ __forceinline__ void bgk_fast(float (&f)[L::Q], float omega) {
+  constexpr int Q = L::Q, NP = (Q - 1) / 2;
+  float rho = f[0];
+  static_for<Q - 1>([&](auto lc) { rho = rho + f[decltype(lc)::value + 1]; });
+  float u[3] = {0.0f, 0.0f, 0.0f};
+  static_for<Q>([&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    static_for<3>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if constexpr (L::c(a, l) == 1) u[a] = u[a] + f[l];
+      if constexpr (L::c(a, l) == -1) u[a] = u[a] - f[l];
+    });
+  });
+  const float inv_rho = __builtin_amdgcn_rcpf(rho);
+  u[0] = u[0] * inv_rho;
+  u[1] = u[1] * inv_rho;
+  u[2] = u[2] * inv_rho;
+  const float A = fmaf(-1.5f, fmaf(u[0], u[0], fmaf(u[1], u[1], u[2] * u[2])), 1.0f);  // 1 - usqr
+  const float orho = omega * rho, keep = 1.0f - omega;
+  // omega rho w per weight class |c|_1 = 0 .. 3
+  float W[4];
+  static_for<4>([&](auto nc) {
+    constexpr int n = decltype(nc)::value;
+    double w = 0.0;
+    for (int l = 0; l < Q; ++l)
+      if (iabs(L::c(0, l)) + iabs(L::c(1, l)) + iabs(L::c(2, l)) == n) w = L::w(l);
+    W[n] = orho * float(w);
+  });
+  static_for<Q>([&](auto lc) {  // the rest population(s)
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l == opp<L>(l)) f[l] = fmaf(keep, f[l], W[0] * A);
+  });
+  static_for<NP>([&](auto kc) {
+    constexpr int l = pair_first<L>(decltype(kc)::value), o = opp<L>(l);
+    constexpr int n1 = iabs(L::c(0, l)) + iabs(L::c(1, l)) + iabs(L::c(2, l));
+    float d = 0.0f;
+    static_for<3>([&](auto ac) {
+      constexpr int a = decltype(ac)::value;
+      if constexpr (L::c(a, l) == 1) d = d + u[a];
+      if constexpr (L::c(a, l) == -1) d = d - u[a];
+    });
+    const float E = fmaf(4.5f * d, d, A), O = 3.0f * d;
+    f[l] = fmaf(keep, f[l], W[n1] * (E + O));
+    f[o] = fmaf(keep, f[o], W[n1] * (E - O));
+  });
+}
+
 // ---- per-cell prescribed values (profiles) of Zou-He / Regularized BCs ----
 constexpr int PROF_FLAG = 26;  // slot of the per-BC value vector that says "prescribed values come from the profile table"
 

@@ -145,7 +145,7 @@ __device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_
 
 // The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
 // run either boundary-condition form of the body in the same allocation).
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN>
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST>
 __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsigned* ldsmeta, T* bcval) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
@@ -244,7 +244,9 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
 
   auto finish = [&](T(&f)[Q], bool fullway) __attribute__((always_inline)) {
     if (!fullway) {
-      if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4)
+      if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4 && FAST)
+        bgk_fast<L>(f, a.omega);  // tolerance-graded (cell.hpp); the default, exact_math=1 selects the bit-exact form below
+      else if constexpr (COLL == XLBHIP_BGK && sizeof(T) == 4)
         collide_bgk_packed<L, GMAX, PIN>(f, a.omega);  // same arithmetic, fewer issue slots (cell.hpp); GMAX: measured best 3 / 1 (with / without BCs)
       else
         collide<L, T, COLL>(f, a.omega, a.extra);
@@ -517,7 +519,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
 // `a.clean[blockIdx.x]` (k_step2_clean, rebuilt with the meta words every run) is block-uniform.  On the 512^3 cavity that
 // is every segment of an interior tile column but its first and last one, 54 % of the items.  (Round 1 tried the same
 // split as separate launches on two streams and lost to launch tails / kernel mixing; one launch has neither.)
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED>
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
 __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
@@ -526,11 +528,11 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   if constexpr (HASBC != 0) {
     if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
-      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN>(a, lds, ldsmeta, bcval);
+      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST>(a, lds, ldsmeta, bcval);
       return;
     }
   }
-  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false)>(a, lds, ldsmeta, bcval);
+  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false), FAST>(a, lds, ldsmeta, bcval);
 }
 
 // clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel

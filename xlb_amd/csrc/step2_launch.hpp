@@ -17,8 +17,19 @@ inline int step2_eff_cap(const StepLaunch& p) {
 }
 inline int step2_eff_swizzle(const StepLaunch& p, unsigned tiles) { return (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0; }
 
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
+static int launch2f(const StepLaunch& p);
+
+// fast_bgk = 1 (opt-in): the tolerance-graded fast BGK body (cell.hpp: bgk_fast).  Measured: 20 % fewer VALU instructions buy
+// 2-4 % (profiles/r02/step2_sweeps.txt) — the kernel is bound by its real memory traffic, not by VALU issue — so the
+// bit-exact body stays the default.
 template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED = XLB_STEP2_PACKED_DEFAULT>
 static int launch2(const StepLaunch& p) {
+  return p.fast_bgk ? launch2f<L, HASBC, TY, TZ, SLAB, PACKED, true>(p) : launch2f<L, HASBC, TY, TZ, SLAB, PACKED, false>(p);
+}
+
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
+static int launch2f(const StepLaunch& p) {
   StepArgs<float, float> a;
   // SLAB: pointers advanced to interior plane 0 (the kernel addresses the ghost planes with negative indices)
   const size_t ghost = (size_t)p.halo * p.ny * p.nz;
@@ -57,7 +68,7 @@ static int launch2(const StepLaunch& p) {
   a.extra.smag_cs = p.smag_cs;
   const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
   a.xcd_swizzle = step2_eff_swizzle(p, tiles);
-  hipLaunchKernelGGL((k_step2<L, float, float, XLBHIP_BGK, HASBC, TY, TZ, SLAB, PACKED>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
+  hipLaunchKernelGGL((k_step2<L, float, float, XLBHIP_BGK, HASBC, TY, TZ, SLAB, PACKED, FAST>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
   XLB_HIP(hipGetLastError());
   return 0;
 }

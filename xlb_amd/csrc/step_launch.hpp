@@ -43,6 +43,7 @@ struct StepLaunch {
   int block_threads;  // 0 = default (256)
   int block_tz;       // threads along z per block, 0 = as many as fit
   int xcd_swizzle;
+  int fast_bgk;   // two-step kernel only: 1 = tolerance-graded fast BGK body (opt-in)
   int fast_math;  // 1: tolerance-graded fast collision where one is built (fp64 KBC: cell.hpp kbc_fast); 0: bit-exact builds only
   hipStream_t stream;
 };
