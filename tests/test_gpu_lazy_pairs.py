@@ -113,3 +113,13 @@ def test_lazy_pairs_can_be_switched_off_and_exported_fields_are_never_deferred()
     stepper2(g_0, g_1, bm2, mm2, 1.2, 0)
     assert stepper2._deferred is None
     assert np.array_equal(g_1.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 1))
+
+
+def test_editing_the_masks_flushes_the_deferred_step():
+    """A deferred step was issued with the masks as they were: touching bc_mask afterwards must run it first."""
+    stepper, (f_0, f_1, bm, mm), lat, obcs, f_np, o_bm, o_mm = setup()
+    stepper(f_0, f_1, bm, mm, 1.2, 0)
+    assert stepper._deferred is not None
+    saved = bm.numpy()  # any access to the mask counts
+    assert stepper._deferred is None and np.array_equal(saved, o_bm)
+    assert np.array_equal(f_1.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 1))

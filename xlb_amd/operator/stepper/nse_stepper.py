@@ -156,8 +156,14 @@ class IncompressibleNavierStokesStepper(Stepper):
         if d is None:
             return
         f_src, f_dst, bcm, miss, omega, t = d
-        f_src._hook = f_dst._hook = None
+        self._unhook(f_src, f_dst, bcm, miss)
         self._native_stepper().step(f_src, f_dst, bcm, miss, omega, t)
+
+    @staticmethod
+    def _unhook(*fields):
+        for fld in fields:
+            if fld is not None:
+                fld._hook = None
 
     def _materialise(self, field, bcm, miss, omega, t):
         """`field` should hold f(t+1) but its buffer holds f(t) (a fused pair passed it by): one single step through a
@@ -179,7 +185,7 @@ class IncompressibleNavierStokesStepper(Stepper):
             if f_0 is f_dst and f_1 is f_src and bc_mask is bcm and missing_mask is miss and float(omega) == om and not (f_0._pinned or f_1._pinned):
                 # the caller swapped the fields: steps t and t + 1 in one pass, f(t) in f_src's buffer -> f(t+2) in f_dst's
                 self._deferred = None
-                f_src._hook = f_dst._hook = None
+                self._unhook(f_src, f_dst, bcm, miss)
                 if not self._native_stepper().step2_eligible(f_src, f_dst, bcm, miss):  # (an option changed in between)
                     self._native_stepper().step(f_src, f_dst, bcm, miss, om, t)
                     return False
@@ -197,7 +203,9 @@ class IncompressibleNavierStokesStepper(Stepper):
         if f_0._hook is not None:  # the source itself is virtual (read it properly first)
             f_0.handle
         self._deferred = (f_0, f_1, bc_mask, missing_mask, float(omega), timestep)
-        f_0._hook = f_1._hook = self._flush_deferred
+        for fld in (f_0, f_1, bc_mask, missing_mask):  # the masks too: editing them must not overtake the deferred step
+            if fld is not None:
+                fld._hook = self._flush_deferred
         import weakref
 
         if not any(r() is self for r in self._ctx._flushers):
