@@ -25,8 +25,10 @@ def torchrun(script, world, **env):
     return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
 
 
-def test_two_ranks_one_gpu_host_staged_halo():
-    out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="host")
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_host_staged_halo(world):
+    """(world 3: a rank with two neighbours, uneven slabs of three different sizes)"""
+    out = torchrun("_gpu_rank_worker.py", world, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="host")
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "GPU_SLAB_OK" in out.stdout
 
