@@ -1060,13 +1060,14 @@ static int check_step_fields(const xlbhip_stepper* s, const xlbhip_field* a, con
 static int fuse2_tile_ty(const xlbhip_ctx* c) {
 #ifdef XLB_TUNE_VARIANTS
   if (opt(c, "fuse2_tile", 0) == 2) return 16;
+  if (opt(c, "fuse2_tile", 0) == 4) return 4;
 #endif
   (void)c;
   return 8;
 }
 static int fuse2_tile_tz(const xlbhip_ctx* c) {
 #ifdef XLB_TUNE_VARIANTS
-  if (opt(c, "fuse2_tile", 0) == 2) return 32;
+  if (opt(c, "fuse2_tile", 0) == 2 || opt(c, "fuse2_tile", 0) == 3) return 32;
 #endif
   (void)c;
   return 64;
@@ -1088,6 +1089,9 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.tile_oy = p.tile_oz = 0;
   p.tile_ty = fuse2_tile_ty(c);
   p.tile_tz = fuse2_tile_tz(c);
+  // D3Q27 KBC: (8 x 48) tiles — 8 waves per block, i.e. 2 per SIMD and 256 VGPRs for the collision (the (8 x 64) tile's 11 waves
+  // leave 168: 3.8 KB of scratch in fp64); the grown tile is 500 cells for 384 outputs, the same ratio as (8 x 64)
+  if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) p.tile_tz = 48;
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -1186,7 +1190,7 @@ static void drop_clean_cache(xlbhip_stepper* s) {
 }
 
 static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
-  if (s->lattice == XLBHIP_D3Q27) return launch_step2_d3q27_bgk(p);
+  if (s->lattice == XLBHIP_D3Q27) return s->collision == XLBHIP_KBC ? launch_step2_d3q27_kbc(p) : launch_step2_d3q27_bgk(p);
   p.clean = nullptr;
   if (p.has_bc && p.meta && opt(s->ctx, "fuse2_clean", 1)) {
     const std::array<int, 5> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, (p.tile_order ? 1 : 0) + 2 * p.tile_oy + 1024 * p.tile_oz, p.xcd_swizzle};
@@ -1319,6 +1323,10 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   StepLaunch p = make_launch(s, src, dst, bcm, miss, 1.0);
   if (!step2_eligible(p, s->lattice, s->collision)) return false;
   if (mode == 1) {
+    // D3Q27 KBC pairs on request only (fuse2 = 2): ~1100 (fp32) / 810 (fast fp64) VALU instructions per cell and 8 waves per CU make
+    // the two-step form issue-bound — 384^3: 2.41 (FP64FP32) / 2.52 (FP32FP32) ms per step against 2.21 / 2.16 of the HBM-bound
+    // single-step kernel (profiles/r02/d3q27_kbc_two_step.txt)
+    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) return false;
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
     const long items = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz) * fuse2_segments(s, p), cus = fill_cus(s->ctx);

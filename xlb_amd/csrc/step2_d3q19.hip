@@ -9,12 +9,15 @@ bool step2_eligible(const StepLaunch& p, int lattice, int collision) {
   // family they are fine on the x end planes, which the two-step kernel leaves to the single-step kernel (edge_ext)
   for (int i = 0; i < p.n_bc && i < 8; ++i)
     if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING && !p.edge_ext) return false;
-  if (!(collision == XLBHIP_BGK && p.compute_dtype == XLBHIP_F32 && p.store_dtype == XLBHIP_F32 && p.nx >= 4 && p.ny % p.tile_ty == 0 &&
-        p.nz % p.tile_tz == 0))
-    return false;
-  if (lattice == XLBHIP_D3Q27)  // built without boundary conditions and without ghost planes only (LDS: 54 population-planes)
-    return p.has_bc == 0 && p.halo == 0 && p.tile_ty == 8 && p.tile_tz == 64;
-  return lattice == XLBHIP_D3Q19 && (p.halo == 0 || p.halo == 2) && (p.has_bc <= 1 || (p.edge_ext && p.halo == 0 && p.nx >= 16)) &&
+  if (!(p.store_dtype == XLBHIP_F32 && p.nx >= 4 && p.ny % p.tile_ty == 0 && p.nz % p.tile_tz == 0)) return false;
+  if (lattice == XLBHIP_D3Q27) {  // built without boundary conditions and without ghost planes only (LDS: 54 population-planes)
+    if (!(p.has_bc == 0 && p.halo == 0 && p.tile_ty == 8)) return false;
+    if (collision == XLBHIP_BGK) return p.compute_dtype == XLBHIP_F32 && p.tile_tz == 64;
+    // KBC: fp32 and fp64 compute, (8 x 48) tiles (api.hip make_launch)
+    // (the bit-exact fp64 collision needs 940 B of scratch there — 12 ms per step: it stays on the single-step kernel)
+    return collision == XLBHIP_KBC && (p.compute_dtype == XLBHIP_F32 || (p.compute_dtype == XLBHIP_F64 && p.fast_math)) && p.tile_tz == 48;
+  }
+  return collision == XLBHIP_BGK && p.compute_dtype == XLBHIP_F32 && lattice == XLBHIP_D3Q19 && (p.halo == 0 || p.halo == 2) && (p.has_bc <= 1 || (p.edge_ext && p.halo == 0 && p.nx >= 16)) &&
          p.n_bc <= MAX_FAST_BCS;
 }
 
@@ -28,6 +31,9 @@ int launch_step2_d3q19_bgk(const StepLaunch& p) {
     if (p.halo) return p.has_bc ? launch2<D3Q19, 1, 16, 32, true>(p) : launch2<D3Q19, 0, 16, 32, true>(p);
     return p.has_bc ? launch2<D3Q19, 1, 16, 32, false>(p) : launch2<D3Q19, 0, 16, 32, false>(p);
   }
+  // smaller tiles on the lifetime-packed ring, several blocks per CU (periodic boxes without ghost planes only)
+  if (p.tile_ty == 8 && p.tile_tz == 32 && !p.halo && !p.has_bc) return launch2<D3Q19, 0, 8, 32, false, true>(p);
+  if (p.tile_ty == 4 && p.tile_tz == 64 && !p.halo && !p.has_bc) return launch2<D3Q19, 0, 4, 64, false, true>(p);
 #else
   XLB_REQUIRE(p.tile_ty == 8 && p.tile_tz == 64, "two-step kernel: only the (8 x 64) tile is built (fuse2_tile=2 needs -DXLB_TUNE_VARIANTS)");
 #endif

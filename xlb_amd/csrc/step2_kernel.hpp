@@ -28,6 +28,9 @@
 #ifndef XLB_PIN_BC
 #define XLB_PIN_BC true
 #endif
+#ifndef XLB_STEP2_MAX_BLOCKS
+#define XLB_STEP2_MAX_BLOCKS 2
+#endif
 #ifndef XLB_STEP2_PLAIN_GMAX
 #define XLB_STEP2_PLAIN_GMAX 1  // pair-group width of the kernel without boundary conditions
 #endif
@@ -84,8 +87,10 @@ struct S2Geom {
   static constexpr int THREADS = (NE + 63) / 64 * 64;    // whole waves covering the grown tile
   static constexpr int LDS_BYTES = S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + (HASBC != 0 ? 3 * NE * 4 + 1024 : 8);  // ring + meta words + BC constants
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
-  // one block per CU (LDS) -> waves per SIMD the register allocation must admit
-  static constexpr int WAVES_PER_SIMD = (THREADS / 64 + 3) / 4;
+  // blocks per CU the LDS admits (one for every tile built by default; XLB_STEP2_MAX_BLOCKS bounds the tuning variants)
+  // -> waves per SIMD the register allocation must admit
+  static constexpr int BLOCKS_PER_CU = (160 * 1024) / LDS_BYTES < XLB_STEP2_MAX_BLOCKS ? (160 * 1024) / LDS_BYTES : XLB_STEP2_MAX_BLOCKS;
+  static constexpr int WAVES_PER_SIMD = (BLOCKS_PER_CU * (THREADS / 64) + 3) / 4;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), i.e. every
@@ -146,12 +151,14 @@ __device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_
 // The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
 // run either boundary-condition form of the body in the same allocation).
 template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST>
-__device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsigned* ldsmeta, T* bcval) {
+__device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsigned* ldsmeta, T* bcval) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
-  static_assert(sizeof(T) == 4, "k_step2 keeps f(t+1) as fp32 in LDS");
+  // f(t+1) lives in LDS in the STORE type: the single-step kernel rounds it to that type on its way through memory, so the
+  // ring holds exactly what two single steps would have stored, whatever the compute type (fp64 KBC: FP64FP32)
+  static_assert(sizeof(S) == 4, "k_step2 keeps f(t+1) as 4-byte store values in LDS");
   // first cell of the buffer that holds population l of plane q (q counted from x_lo - 1; uniform)
   auto ring = [&](auto lc, int q) __attribute__((always_inline)) -> int {
     constexpr int l = decltype(lc)::value;
@@ -387,21 +394,21 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
     finish(f, fullway);
     if (act_a) {
       if constexpr (!PACKED) {
-        T* dst = lds + (q % 3) * (Q * NE) + t;
+        S* dst = lds + (q % 3) * (Q * NE) + t;
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
-          dst[l * NE] = to_compute<T, S>(to_store<S, T>(f[l]));  // f(t+1) passes through the store precision
+          dst[l * NE] = to_store<S, T>(f[l]);  // f(t+1) passes through the store precision
         });
       } else {
         // one pointer per group buffer + a compile-time offset per population (pointer form: see phase B)
-        T* gb[3];
+        S* gb[3];
         static_for<3>([&](auto gc) {
           constexpr int g = decltype(gc)::value, life = R::glife(g);
           gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3)) * R::gcount(g)) * NE + t;
         });
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
-          gb[R::group(l)][R::gidx(l) * NE] = to_compute<T, S>(to_store<S, T>(f[l]));
+          gb[R::group(l)][R::gidx(l) * NE] = to_store<S, T>(f[l]);
         });
       }
       if constexpr (HASBC != 0) ldsmeta[(q % 3) * NE + t] = w;
@@ -422,19 +429,19 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
     }
     if (mall == 0u) {  // fluid wave (or only fullway / equilibrium lanes): one scalar branch, then straight-line reads
       if constexpr (!PACKED) {
-        const T* base[3];  // index c_x + 1 -> plane x - c_x
+        const S* base[3];  // index c_x + 1 -> plane x - c_x
         base[0] = lds + ((q0 + 1) % 3) * (Q * NE);
         base[1] = lds + (q0 % 3) * (Q * NE);
         base[2] = lds + ((q0 - 1) % 3) * (Q * NE);
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
           constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-          f[l] = base[cx + 1][l * NE + ctr_b - cy * EZ - cz];
+          f[l] = to_compute<T, S>(base[cx + 1][l * NE + ctr_b - cy * EZ - cz]);
         });
       } else {
         // (pointer + immediate form; indexing one array with run-time buffer offsets — lds[ring(l, q) + ...] — compiles to
         // the same instruction mix but measured 9 % slower on the periodic box: profiles/r02/step2_sweeps.txt)
-        const T* gb[3];  // group g = c_x + 1 comes from plane q0 - c_x
+        const S* gb[3];  // group g = c_x + 1 comes from plane q0 - c_x
         static_for<3>([&](auto gc) {
           constexpr int g = decltype(gc)::value, life = R::glife(g);
           const int qs = q0 - (g - 1);
@@ -443,7 +450,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
           constexpr int cy = L::c(1, l), cz = L::c(2, l);
-          f[l] = gb[R::group(l)][R::gidx(l) * NE + ctr_b - cy * EZ - cz];
+          f[l] = to_compute<T, S>(gb[R::group(l)][R::gidx(l) * NE + ctr_b - cy * EZ - cz]);
         });
       }
     } else {
@@ -455,7 +462,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
         constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
         const int idx_pull = ring(lc, q0 - cx) + ctr_b - cy * EZ - cz;
         const int idx_own = ring(std::integral_constant<int, opp<L>(l)>{}, q0) + ctr_b;
-        got[l] = lds[((mm >> l) & 1u) ? idx_own : idx_pull];
+        got[l] = to_compute<T, S>(lds[((mm >> l) & 1u) ? idx_own : idx_pull]);
         f[l] = got[l];
       });
       hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(meta_kind(w) == K_HW_MOVING) != 0ull);
@@ -509,6 +516,9 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, T* lds, unsi
     lds_barrier();  // every reader of the buffers about to be overwritten is done
     finish_a(raw, fix, w_raw, mall_raw, d + 3, true);  // plane x + 2
     w_raw = wa;
+    // (KBC: keep the scheduler from hoisting the next plane's pulls above the collision — 27 more live registers there
+    // put the fp64 body into scratch)
+    if constexpr ((COLL & 3) != XLBHIP_BGK) __builtin_amdgcn_sched_barrier(0);
     issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
     lds_barrier();  // plane x + 2 visible
   }
@@ -523,7 +533,7 @@ template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool S
 __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
-  __shared__ T lds[R::PLANES * G::NE];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
+  __shared__ S lds[R::PLANES * G::NE];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
   __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   if constexpr (HASBC != 0) {

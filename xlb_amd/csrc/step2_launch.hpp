@@ -17,7 +17,7 @@ inline int step2_eff_cap(const StepLaunch& p) {
 }
 inline int step2_eff_swizzle(const StepLaunch& p, unsigned tiles) { return (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0; }
 
-template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T = float, int COLL = XLBHIP_BGK>
 static int launch2f(const StepLaunch& p);
 
 // fast_bgk = 1 (opt-in): the tolerance-graded fast BGK body (cell.hpp: bgk_fast).  Measured: 20 % fewer VALU instructions buy
@@ -28,9 +28,11 @@ static int launch2(const StepLaunch& p) {
   return p.fast_bgk ? launch2f<L, HASBC, TY, TZ, SLAB, PACKED, true>(p) : launch2f<L, HASBC, TY, TZ, SLAB, PACKED, false>(p);
 }
 
-template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
+// T / COLL: compute type and collision (cell.hpp collide<>) of the instantiation; the store type is always fp32
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T, int COLL>
 static int launch2f(const StepLaunch& p) {
-  StepArgs<float, float> a;
+  static_assert(HASBC == 0 || (sizeof(T) == 4 && COLL == XLBHIP_BGK), "boundary-condition tables of the two-step kernel are fp32 / BGK");
+  StepArgs<T, float> a;
   // SLAB: pointers advanced to interior plane 0 (the kernel addresses the ghost planes with negative indices)
   const size_t ghost = (size_t)p.halo * p.ny * p.nz;
   a.src = static_cast<const float*>(p.src) + ghost;
@@ -45,7 +47,7 @@ static int launch2f(const StepLaunch& p) {
   a.tile_oy = p.tile_oy;
   a.tile_oz = p.tile_oz;
   a.bc_kind = p.tab_kind;
-  a.bc_values = static_cast<const float*>(p.tab_values);
+  a.bc_values = static_cast<const T*>(p.tab_values);
   a.prof_keys = nullptr;  // (profile BCs are Zou-He / Regularized: single-step kernel)
   a.prof_vals = nullptr;
   a.n_prof = 0;
@@ -63,12 +65,12 @@ static int launch2f(const StepLaunch& p) {
   a.x_begin = p.x_begin;
   a.x_count = p.x_count;
   a.nzq = p.nz;
-  a.omega = static_cast<float>(p.omega);
+  a.omega = static_cast<T>(p.omega);
   a.extra.force[0] = a.extra.force[1] = a.extra.force[2] = 0.0;
   a.extra.smag_cs = p.smag_cs;
   const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
   a.xcd_swizzle = step2_eff_swizzle(p, tiles);
-  hipLaunchKernelGGL((k_step2<L, float, float, XLBHIP_BGK, HASBC, TY, TZ, SLAB, PACKED, FAST>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
+  hipLaunchKernelGGL((k_step2<L, T, float, COLL, HASBC, TY, TZ, SLAB, PACKED, FAST>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
   XLB_HIP(hipGetLastError());
   return 0;
 }

@@ -192,6 +192,7 @@ int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
 int launch_step2_d3q27_bgk(const StepLaunch& p);
+int launch_step2_d3q27_kbc(const StepLaunch& p);
 int step2_build_clean(const StepLaunch& p, uint8_t* out);
 int step2_items(const StepLaunch& p);
 int launch_step_d2q9_ext(const StepLaunch& p, int coll);
