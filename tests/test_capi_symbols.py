@@ -70,7 +70,7 @@ def test_lattice_tables_in_the_kernels_match_python_without_a_device():
 
 
 def test_two_step_kernel_does_not_spill(tmp_path):
-    """k_step2 counts its outstanding vector-memory operations by hand (s_waitcnt vmcnt(19) behind inline-asm loads,
+    """k_step2 counts its outstanding vector-memory operations by hand (a counted s_waitcnt vmcnt(N) behind inline-asm loads,
     step2_kernel.hpp): a register spill adds scratch loads/stores the count does not know about and may copy a register
     an asm load is still writing.  The kernel sits close to the SGPR/VGPR limits, so guard the compiled result."""
     import shutil
@@ -88,14 +88,19 @@ def test_two_step_kernel_does_not_spill(tmp_path):
     assert "scratch_" not in text, "k_step2 spills to scratch"
     sizes = [int(m) for m in re.findall(r"\.private_segment_fixed_size:\s*(\d+)", text)]
     assert sizes and all(v == 0 for v in sizes), sizes
-    # The hand-placed `s_waitcnt vmcnt(19)` (inline asm, between ;;#ASMSTART / ;;#ASMEND) retires the redirected own-cell loads of a
-    # boundary wave while leaving the 19 stores of the phase B that ran in between in flight.  That is only correct while
-    # at least 19 vector-memory operations are issued between those loads and the wait: check it on the compiled code —
-    # walking back from every such wait, 19 global stores must come before the previous block of asm fix-up loads.
+    # The hand-placed `s_waitcnt vmcnt(N)` (inline asm, between ;;#ASMSTART / ;;#ASMEND; N = the stores phase B issues per thread: 19, or
+    # 5 with the staged 16-byte stores) retires the redirected own-cell loads of a boundary wave while leaving the N stores of the phase B
+    # that ran in between in flight.  That is only correct while at least N vector-memory operations are issued between those loads and
+    # the wait: check it on the compiled code — walking back from every such wait, N global stores must come before the previous block
+    # of asm fix-up loads.
     lines = text.splitlines()
-    waits = [i for i, l in enumerate(lines) if l.strip() == "s_waitcnt vmcnt(19)" and lines[i - 1].strip() == ";;#ASMSTART"]
-    assert len(waits) >= 2, "hand-placed vmcnt(19) not found in the boundary-condition variants"
-    for w in waits:
+    waits = []
+    for i, l in enumerate(lines):
+        m = re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", l.strip())
+        if m and int(m.group(1)) > 0 and lines[i - 1].strip() == ";;#ASMSTART":
+            waits.append((i, int(m.group(1))))
+    assert len(waits) >= 2, "hand-placed counted vmcnt not found in the boundary-condition variants"
+    for w, need in waits:
         stores = 0
         i = w - 2
         while i > 0:
@@ -107,4 +112,4 @@ def test_two_step_kernel_does_not_spill(tmp_path):
             if re.match(r"^_ZN3xlb7k_step2", t):
                 break
             i -= 1
-        assert stores >= 19, f"only {stores} stores between the fix-up loads and the counted wait at line {w}"
+        assert stores >= need, f"only {stores} stores between the fix-up loads and the counted wait vmcnt({need}) at line {w}"

@@ -59,3 +59,13 @@ int step2_build_clean(const StepLaunch& p, uint8_t* out) {
 int step2_items(const StepLaunch& p) { return (p.ny / p.tile_ty) * (p.nz / p.tile_tz) * step2_eff_segments(p); }
 
 }  // namespace xlb
+
+#ifdef XLB_STEP2_TRACE
+// debug builds only (tools/step2_phase_trace.py): the phase stamps of the last launch
+extern "C" int xlbhip_debug_step2_trace(unsigned long long* out, int n) {
+  constexpr int N = xlb::TRACE_PLANES * xlb::TRACE_WAVES * xlb::TRACE_EVENTS;
+  if (n < N) return N;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(xlb::g_step2_trace), sizeof(unsigned long long) * N) == hipSuccess ? 0 : -1;
+}
+#endif

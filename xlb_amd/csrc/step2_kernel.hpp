@@ -28,6 +28,12 @@
 #ifndef XLB_PIN_BC
 #define XLB_PIN_BC true
 #endif
+#ifndef XLB_STEP2_ROWMAP
+#define XLB_STEP2_ROWMAP 0
+#endif
+#ifndef XLB_STEP2_STAGE
+#define XLB_STEP2_STAGE 0
+#endif
 #ifndef XLB_STEP2_MAX_BLOCKS
 #define XLB_STEP2_MAX_BLOCKS 2
 #endif
@@ -39,6 +45,25 @@
 #endif
 
 namespace xlb {
+
+// -DXLB_STEP2_TRACE=1|2 (tools/step2_phase_trace.py, never in the shipped build): shader-clock stamps of the steady-state loop's phases,
+// per wave, for one block and a few planes.  2 additionally drains vmcnt at the top of finish_a, which separates "waiting for the pulls"
+// from the collision (and perturbs the pipeline: the stores drain too).
+#ifdef XLB_STEP2_TRACE
+constexpr int TRACE_PLANES = 6, TRACE_EVENTS = 8, TRACE_WAVES = 11, TRACE_FIRST = 40, TRACE_BLOCK = 300;
+static __device__ unsigned long long g_step2_trace[TRACE_PLANES * TRACE_WAVES * TRACE_EVENTS];
+__device__ __forceinline__ void trace_stamp(int d, int e) {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long tm;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+  if (blockIdx.x == TRACE_BLOCK && d >= TRACE_FIRST && d < TRACE_FIRST + TRACE_PLANES && (threadIdx.x & 63) == 0)
+    g_step2_trace[((d - TRACE_FIRST) * TRACE_WAVES + (threadIdx.x >> 6)) * TRACE_EVENTS + e] = tm;
+  __builtin_amdgcn_sched_barrier(0);
+}
+#define XLB_TRACE(d, e) trace_stamp(d, e)
+#else
+#define XLB_TRACE(d, e)
+#endif
 
 // LDS ring of f(t+1), packed by population LIFETIME.  Plane p of f(t+1) is produced by phase A of iteration p - 2 and
 // consumed by phase B of plane p + c_x (the pull f_l(x) <- f_l(x - c_x)): its c_x = -1 populations one iteration later,
@@ -85,7 +110,15 @@ struct S2Geom {
   static constexpr int NE = EY * EZ;                     // cells of f(t+1) per plane slot (grown tile)
   static constexpr int NB = TY * TZ;                     // output cells per plane
   static constexpr int THREADS = (NE + 63) / 64 * 64;    // whole waves covering the grown tile
-  static constexpr int LDS_BYTES = S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + (HASBC != 0 ? 3 * NE * 4 + 1024 : 8);  // ring + meta words + BC constants
+  // STAGE: phase B hands its results to the memory pipeline as 16-byte stores — each wave writes the 19 values of its 64 cells (one z
+  // row of the tile) to a wave-private LDS area and reads them back four cells of one population per lane: 5 store instructions per
+  // wave and plane instead of 19 (the vector-memory pipeline is paid per instruction).  Needs the packed ring's room: 19 x 64 x 4 B per wave.
+  static constexpr int EXTRA_BYTES = HASBC != 0 ? 3 * NE * 4 + 1024 : 8;  // meta words + BC constants
+  static constexpr bool STAGE = XLB_STEP2_STAGE != 0 && PACKED && TZ == 64 &&
+                                S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + NB * L::Q * 4 + EXTRA_BYTES <= 160 * 1024;  // (D3Q27: no room)
+  static constexpr int STAGE_ELEMS = STAGE ? (NB / 64) * L::Q * 64 : 0;
+  static constexpr int N_STORES = STAGE ? (L::Q + 3) / 4 : L::Q;  // vector-memory stores per phase-B thread and plane
+  static constexpr int LDS_BYTES = S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + STAGE_ELEMS * 4 + EXTRA_BYTES;  // ring + staging + meta words + BC constants
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
   // blocks per CU the LDS admits (one for every tile built by default; XLB_STEP2_MAX_BLOCKS bounds the tuning variants)
   // -> waves per SIMD the register allocation must admit
@@ -213,7 +246,12 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   // ---- phase-A cell of this thread (grown tile, periodic images) ----
   const bool act_a = t < NE;
   const int ta = act_a ? t : NE - 1;
-  const int ja = ta / EZ, ka = ta % EZ;
+  // row-aligned lanes ((TY x 64) tiles): wave j < EY pulls the 64 interior cells of grown row j (for c_z = 0 one aligned 256-byte
+  // piece per pull instead of the tail of one row + the head of the next), the last wave the two halo columns of all rows
+  constexpr bool ROWMAP = XLB_STEP2_ROWMAP != 0 && TZ == 64;
+  const int ja = !ROWMAP ? ta / EZ : (ta < G::EY * 64 ? ta / 64 : (ta - G::EY * 64) / 2);
+  const int ka = !ROWMAP ? ta % EZ : (ta < G::EY * 64 ? 1 + ta % 64 : ((ta & 1) ? EZ - 1 : 0));
+  const int slot_a = ja * EZ + ka;  // my cell inside a grown-tile slot
   int ya = ty0 - 1 + ja, za = tz0 - 1 + ka;
   ya = ya < 0 ? ya + ny : (ya >= ny ? ya - ny : ya);
   za = za < 0 ? za + nz : (za >= nz ? za - nz : za);
@@ -235,6 +273,19 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   zb = zb >= nz ? zb - nz : zb;
   const unsigned cell_b = (unsigned)yb * (unsigned)nz + (unsigned)zb;
   const int ctr_b = (jb + 1) * EZ + (kb + 1);  // my cell inside a grown-tile slot
+  // staged stores (S2Geom::STAGE): lane i of a phase-B wave stores cells 4 (i % 16) .. + 3 of the wave's row for population 4 g + i / 16;
+  // byte offset of that piece from population 4 g's row of the plane (the tile's z shift is a multiple of 4: a piece never straddles the wrap)
+  // (the last group holds Q % 4 populations: its idle lanes repeat the last one — same bytes to the same address, no branch around the store)
+  size_t stage_off = 0, stage_off_last = 0;
+  constexpr int SUB_LAST = (Q - 1) % 4;
+  const int sub = (t >> 4) & 3, sub_last = sub < SUB_LAST ? sub : SUB_LAST;
+  if constexpr (G::STAGE) {
+    int zc = tz0 + 4 * (t & 15);
+    zc = zc >= nz ? zc - nz : zc;
+    const size_t cell_off = (size_t)yb * (unsigned)nz + (unsigned)zc;
+    stage_off = ((size_t)sub * a.plane_stride + cell_off) * ES;
+    stage_off_last = ((size_t)sub_last * a.plane_stride + cell_off) * ES;
+  }
 
   // logical plane p -> the plane phase A works on: without ghost planes x is periodic; with them planes past x_hi
   // are prefetches whose results are discarded (clamped, so that they stay inside the allocation)
@@ -369,13 +420,13 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
       if (mall != 0u) {  // wave-uniform: some lane of this wave has redirected pulls
         // The fix-up loads are invisible to the compiler: wait for them here (boundary waves only).
         // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
-        // stores of the phase B that just ran (waves that own output cells) and possibly the meta prefetch,
-        // so vmcnt(Q) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
+        // stores of the phase B that just ran (waves that own output cells: N_STORES each) and possibly the meta prefetch,
+        // so vmcnt(N_STORES) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
         // which made hull tiles 3x slower than fluid tiles).  Extra younger operations only make this safer.
-        static_assert(Q == 19, "vmcnt immediate below assumes 19 stores per phase-B thread");
+        static_assert(G::N_STORES <= 63, "vmcnt immediate");
         // (in the prologue no phase B has run yet: nothing younger, so drain everything)
         if (steady && __builtin_amdgcn_readfirstlane(t) < G::NB)
-          asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::N_STORES) : "memory");  // = the stores phase_b issues per thread, no more
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -394,7 +445,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     finish(f, fullway);
     if (act_a) {
       if constexpr (!PACKED) {
-        S* dst = lds + (q % 3) * (Q * NE) + t;
+        S* dst = lds + (q % 3) * (Q * NE) + slot_a;
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
           dst[l * NE] = to_store<S, T>(f[l]);  // f(t+1) passes through the store precision
@@ -404,14 +455,14 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         S* gb[3];
         static_for<3>([&](auto gc) {
           constexpr int g = decltype(gc)::value, life = R::glife(g);
-          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3)) * R::gcount(g)) * NE + t;
+          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3)) * R::gcount(g)) * NE + slot_a;
         });
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
           gb[R::group(l)][R::gidx(l) * NE] = to_store<S, T>(f[l]);
         });
       }
-      if constexpr (HASBC != 0) ldsmeta[(q % 3) * NE + t] = w;
+      if constexpr (HASBC != 0) ldsmeta[(q % 3) * NE + slot_a] = w;
     }
   };
 
@@ -473,6 +524,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     }
     finish(f, fullway);
   };
+  // Tried and rejected (profiles/r02/step2_sweeps.txt): pulls running TWO planes ahead (second register buffer, loop unrolled by
+  // two; 153 VGPRs) — 0.5 % on the periodic box, 1 % on the cavity: the memory latency behind one phase B is not what the waves wait for.
   // Tried and rejected: issuing the 19 stores from EVERY wave outside the branch (buffer stores, idle waves aimed past
   // the end of the buffer) makes hipcc's vmcnt model exact — with the stores inside `if (act_b)` it waits for the
   // prefetched pulls with vmcnt(19)...vmcnt(1), i.e. drains the wave's own stores every plane — but ran 9 % SLOWER
@@ -481,12 +534,29 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     if (!act_b) return;  // whole waves (NB % 64 == 0)
     T f[Q];
     phase_b_compute(f, d);
-    static_for<Q>([&](auto lc) {
-      constexpr int l = decltype(lc)::value;
-      S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
-      S v[1] = {to_store<S, T>(f[l])};
-      st_aligned<S, 1, true>(drow, cell_b * ES, v);
-    });
+    if constexpr (G::STAGE) {
+      // the wave's 64 cells are one z row of the tile: population-major into the wave's staging area, back as (population, 4 cells)
+      S* st = lds + R::PLANES * NE + (t >> 6) * (Q * 64);
+      const int lane = t & 63;
+      static_for<Q>([&](auto lc) { st[decltype(lc)::value * 64 + lane] = to_store<S, T>(f[decltype(lc)::value]); });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS operations of one wave complete in order; this orders the compiler's view too)
+      char* xrow = reinterpret_cast<char*>(a.dst + (ptrdiff_t)x * pc);  // uniform
+      static_for<G::N_STORES>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        constexpr bool last = 4 * g + 3 >= Q;
+        typedef typename VecOf<S, 4>::aligned V4;
+        const V4 v = *reinterpret_cast<const V4*>(st + (4 * g + (last ? sub_last : sub)) * 64 + (lane & 15) * 4);
+        __builtin_nontemporal_store(v, reinterpret_cast<V4*>(xrow + (size_t)(4 * g) * a.plane_stride * ES + (last ? stage_off_last : stage_off)));
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging area is rewritten by the next plane's phase B
+    } else {
+      static_for<Q>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        S* drow = a.dst + (size_t)l * a.plane_stride + (ptrdiff_t)x * pc;  // uniform
+        S v[1] = {to_store<S, T>(f[l])};
+        st_aligned<S, 1, true>(drow, cell_b * ES, v);
+      });
+    }
   };
 
   // Plane x_lo + p is plane q = p + 1 of the ring (p = -1: the periodic image / ghost plane below the segment).
@@ -512,15 +582,25 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     const int d = x - x_lo;
     unsigned wa = 0;
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
+    XLB_TRACE(d, 0);
     phase_b(x, d);
+    XLB_TRACE(d, 2);
     lds_barrier();  // every reader of the buffers about to be overwritten is done
+    XLB_TRACE(d, 3);
+#if defined(XLB_STEP2_TRACE) && XLB_STEP2_TRACE == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XLB_TRACE(d, 4);
+#endif
     finish_a(raw, fix, w_raw, mall_raw, d + 3, true);  // plane x + 2
+    XLB_TRACE(d, 5);
     w_raw = wa;
     // (KBC: keep the scheduler from hoisting the next plane's pulls above the collision — 27 more live registers there
     // put the fp64 body into scratch)
     if constexpr ((COLL & 3) != XLBHIP_BGK) __builtin_amdgcn_sched_barrier(0);
     issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
+    XLB_TRACE(d, 6);
     lds_barrier();  // plane x + 2 visible
+    XLB_TRACE(d, 7);
   }
 }
 
@@ -533,7 +613,7 @@ template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool S
 __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED>;
-  __shared__ S lds[R::PLANES * G::NE];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
+  __shared__ S lds[R::PLANES * G::NE + G::STAGE_ELEMS];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
   __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   if constexpr (HASBC != 0) {

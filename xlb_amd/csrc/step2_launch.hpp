@@ -6,7 +6,7 @@
 namespace xlb {
 
 #ifndef XLB_STEP2_PACKED_DEFAULT
-#define XLB_STEP2_PACKED_DEFAULT false
+#define XLB_STEP2_PACKED_DEFAULT true
 #endif
 // effective launch geometry (shared by the kernel launch and the clean-flag pass: both must map blocks alike)
 inline int step2_eff_segments(const StepLaunch& p) { return (p.x_segments > 1 && p.x_count >= 8 * p.x_segments) ? p.x_segments : 1; }
