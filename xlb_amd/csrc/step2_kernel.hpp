@@ -12,8 +12,9 @@
 // 2 + 2.  Arithmetic is the same per-cell code (cell.hpp) in the same order, so the result is
 // bit-identical to two single steps (tests/test_gpu_stepper.py::test_two_step_fusion_*).
 //
-// Restrictions (the launcher falls back to the single-step kernel otherwise): D3Q19; fp32 compute and store;
-// ny % TY == 0, nz % TZ == 0; BGK / basic boundary conditions; fields without ghost planes (x wraps here) or with
+// Restrictions (the launcher falls back to the single-step kernel otherwise — step2_eligible): fp32 store (f(t+1) sits in LDS in the
+// store type); D3Q19 BGK fp32 with basic boundary conditions, D3Q27 BGK fp32 and (on request) KBC fp32 / fast fp64 without them;
+// ny % TY == 0, nz % TZ == 0; fields without ghost planes (x wraps here) or — D3Q19 — with
 // TWO ghost planes per side (slab decomposition: phase A also computes f(t+1) on the ghost planes -1 and nx from
 // the neighbours' f(t) — all populations of their edge plane and the inward-moving ones of the plane behind it).
 #pragma once
@@ -27,6 +28,12 @@
 #endif
 #ifndef XLB_PIN_BC
 #define XLB_PIN_BC true
+#endif
+#ifndef XLB_STEP2_SLACK
+#define XLB_STEP2_SLACK 1  // the clean work items of a BC kernel run on the slack ring (one barrier per plane): cavity 512^3 -3.5 %
+#endif
+#ifndef XLB_STEP2_SLACK_PLAIN
+#define XLB_STEP2_SLACK_PLAIN 0  // ... the kernel without boundary conditions does not: periodic 512^3 +3.5 % with it (profiles/r02/step2_sweeps.txt)
 #endif
 #ifndef XLB_STEP2_ROWMAP
 #define XLB_STEP2_ROWMAP 0
@@ -74,13 +81,16 @@ __device__ __forceinline__ void trace_stamp(int d, int e) {
 // populations of plane x — every group must still be there then, so the c_x = -1 group gets a second buffer (43 / 63).
 // (Serving those reads by letting phase A pre-write the value into the entry phase B pulls from was built and dropped:
 // two adjacent solid cells need two different values in the same entry.)
-// PACKED = false keeps three whole planes ([plane % 3][population][cell], round 1's layout): measured 5-7 % FASTER for
-// D3Q19 on the periodic box and 1 % on the cavity (same box, profiles/r02/sweeps.md) — with one block per CU either way
-// the bytes saved buy nothing at 512^3 (a 12 x 64 tile does not divide 512 and needs <= 128 VGPRs, 16 x 32 is slower),
-// and the packed form costs ~20 more address instructions per plane in a kernel bound by VALU issue.  D3Q27 needs it.
-template <class L, int HASBC, bool PACKED>
+// PACKED = false keeps three whole planes ([plane % 3][population][cell], round 1's layout).  With pointer-per-buffer addressing the two
+// forms run alike for D3Q19 (periodic 512^3 2.28 vs 2.29-2.32 ms/step, cavity 2.40-2.42 vs 2.41-2.44: profiles/r02/step2_sweeps.txt); the
+// packed one is the default because D3Q27 needs it and the room it leaves pays for the slack ring of the clean work items.
+// SLACK: one more buffer per population, so that phase A of plane x + 2 may WRITE while phase B of plane x still READS (no buffer
+// phase B(x) reads — planes x - 1 / x / x + 1 of the c_x = +1 / 0 / -1 groups — is the one that receives plane x + 2): the barrier
+// between the two phases goes away, every wave runs its phase B and its phase A back to back and the waves without output cells
+// (3 of 11) start phase A at once.  2 + 3 + 4 buffers: D3Q19 5 x 2 + 9 x 3 + 5 x 4 = 57 population-planes again.
+template <class L, int HASBC, bool PACKED, bool SLACK = false>
 struct S2Ring {
-  static constexpr int life(int l) { return !PACKED ? 3 : (L::c(0, l) == -1 ? (HASBC != 0 ? 2 : 1) : (L::c(0, l) == 0 ? 2 : 3)); }
+  static_assert(!SLACK || (PACKED && HASBC == 0), "the slack ring is the lifetime-packed one, BC-free body");
   // layout: group-major — [c_x = -1 group: life x n_m planes][c_x = 0: 2 x n_z][c_x = +1: 3 x n_p], a plane buffer of a
   // group is contiguous, so that one VGPR base per group + an immediate offset per population addresses everything
   static constexpr int group(int l) { return L::c(0, l) + 1; }  // 0: c_x = -1, 1: c_x = 0, 2: c_x = +1
@@ -94,7 +104,13 @@ struct S2Ring {
     for (int m = 0; m < l; ++m) n += group(m) == group(l) ? 1 : 0;
     return n;
   }
-  static constexpr int glife(int g) { return !PACKED ? 3 : (g == 0 ? (HASBC != 0 ? 2 : 1) : (g == 1 ? 2 : 3)); }
+  static constexpr int glife(int g) { return !PACKED ? 3 : (g == 0 ? (HASBC != 0 ? 2 : 1) : (g == 1 ? 2 : 3)) + (SLACK ? 1 : 0); }
+  // buffer of plane q (counted from x_lo - 1) in a group of `life` buffers
+  template <int life>
+  static __device__ __forceinline__ int buf(int q) {
+    static_assert(life >= 1 && life <= 4, "ring life");
+    return life == 1 ? 0 : (life == 2 ? (q & 1) : (life == 3 ? q % 3 : (q & 3)));
+  }
   static constexpr int gbase(int g) {  // first population-plane of group g
     int b = 0;
     for (int k = 0; k < g; ++k) b += glife(k) * gcount(k);
@@ -114,11 +130,17 @@ struct S2Geom {
   // row of the tile) to a wave-private LDS area and reads them back four cells of one population per lane: 5 store instructions per
   // wave and plane instead of 19 (the vector-memory pipeline is paid per instruction).  Needs the packed ring's room: 19 x 64 x 4 B per wave.
   static constexpr int EXTRA_BYTES = HASBC != 0 ? 3 * NE * 4 + 1024 : 8;  // meta words + BC constants
+  // the BC-free body (the whole kernel, or the clean work items of a BC kernel) runs on the slack ring where that fits the LDS
+  static constexpr int PLANES_BC = S2Ring<L, HASBC, PACKED>::PLANES;
+  static constexpr int PLANES_SLACK = S2Ring<L, 0, true, true>::PLANES;
+  static constexpr bool SLACK = XLB_STEP2_SLACK != 0 && PACKED && PLANES_SLACK * NE * 4 + EXTRA_BYTES <= 160 * 1024;
+  static constexpr bool SLACK_USED = SLACK && (HASBC != 0 || XLB_STEP2_SLACK_PLAIN != 0);
+  static constexpr int RING_PLANES = SLACK_USED && PLANES_SLACK > PLANES_BC ? PLANES_SLACK : PLANES_BC;
   static constexpr bool STAGE = XLB_STEP2_STAGE != 0 && PACKED && TZ == 64 &&
-                                S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + NB * L::Q * 4 + EXTRA_BYTES <= 160 * 1024;  // (D3Q27: no room)
+                                RING_PLANES * NE * 4 + NB * L::Q * 4 + EXTRA_BYTES <= 160 * 1024;  // (D3Q27: no room)
   static constexpr int STAGE_ELEMS = STAGE ? (NB / 64) * L::Q * 64 : 0;
   static constexpr int N_STORES = STAGE ? (L::Q + 3) / 4 : L::Q;  // vector-memory stores per phase-B thread and plane
-  static constexpr int LDS_BYTES = S2Ring<L, HASBC, PACKED>::PLANES * NE * 4 + STAGE_ELEMS * 4 + EXTRA_BYTES;  // ring + staging + meta words + BC constants
+  static constexpr int LDS_BYTES = RING_PLANES * NE * 4 + STAGE_ELEMS * 4 + EXTRA_BYTES;  // ring + staging + meta words + BC constants
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the LDS");
   // blocks per CU the LDS admits (one for every tile built by default; XLB_STEP2_MAX_BLOCKS bounds the tuning variants)
   // -> waves per SIMD the register allocation must admit
@@ -183,10 +205,10 @@ __device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_
 
 // The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
 // run either boundary-condition form of the body in the same allocation).
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST>
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST, bool SLACK = false>
 __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsigned* ldsmeta, T* bcval) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
-  using R = S2Ring<L, HASBC, PACKED>;
+  using R = S2Ring<L, HASBC, PACKED, SLACK>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
   // f(t+1) lives in LDS in the STORE type: the single-step kernel rounds it to that type on its way through memory, so the
@@ -199,8 +221,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
       return (q % 3) * (Q * NE) + l * NE;
     } else {
       constexpr int g = R::group(l), life = R::glife(g);
-      const int buf = life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3);
-      return (R::gbase(g) + buf * R::gcount(g)) * NE + R::gidx(l) * NE;
+      return (R::gbase(g) + R::template buf<life>(q) * R::gcount(g)) * NE + R::gidx(l) * NE;
     }
   };
 
@@ -455,7 +476,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         S* gb[3];
         static_for<3>([&](auto gc) {
           constexpr int g = decltype(gc)::value, life = R::glife(g);
-          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (q & 1) : q % 3)) * R::gcount(g)) * NE + slot_a;
+          gb[g] = lds + (R::gbase(g) + R::template buf<life>(q) * R::gcount(g)) * NE + slot_a;
         });
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
@@ -496,7 +517,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         static_for<3>([&](auto gc) {
           constexpr int g = decltype(gc)::value, life = R::glife(g);
           const int qs = q0 - (g - 1);
-          gb[g] = lds + (R::gbase(g) + (life == 1 ? 0 : (life == 2 ? (qs & 1) : qs % 3)) * R::gcount(g)) * NE;
+          gb[g] = lds + (R::gbase(g) + R::template buf<life>(qs) * R::gcount(g)) * NE;
         });
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
@@ -536,7 +557,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     phase_b_compute(f, d);
     if constexpr (G::STAGE) {
       // the wave's 64 cells are one z row of the tile: population-major into the wave's staging area, back as (population, 4 cells)
-      S* st = lds + R::PLANES * NE + (t >> 6) * (Q * 64);
+      S* st = lds + G::RING_PLANES * NE + (t >> 6) * (Q * 64);
       const int lane = t & 63;
       static_for<Q>([&](auto lc) { st[decltype(lc)::value * 64 + lane] = to_store<S, T>(f[decltype(lc)::value]); });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (LDS operations of one wave complete in order; this orders the compiler's view too)
@@ -585,7 +606,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     XLB_TRACE(d, 0);
     phase_b(x, d);
     XLB_TRACE(d, 2);
-    lds_barrier();  // every reader of the buffers about to be overwritten is done
+    if constexpr (!SLACK) lds_barrier();  // every reader of the buffers about to be overwritten is done (the slack ring has a spare buffer instead)
     XLB_TRACE(d, 3);
 #if defined(XLB_STEP2_TRACE) && XLB_STEP2_TRACE == 2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -612,17 +633,16 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
 template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
 __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
-  using R = S2Ring<L, HASBC, PACKED>;
-  __shared__ S lds[R::PLANES * G::NE + G::STAGE_ELEMS];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
+  __shared__ S lds[G::RING_PLANES * G::NE + G::STAGE_ELEMS];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
   __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
   if constexpr (HASBC != 0) {
     if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
-      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST>(a, lds, ldsmeta, bcval);
+      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST, G::SLACK>(a, lds, ldsmeta, bcval);
       return;
     }
   }
-  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false), FAST>(a, lds, ldsmeta, bcval);
+  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false), FAST, (HASBC == 0 && G::SLACK && XLB_STEP2_SLACK_PLAIN != 0)>(a, lds, ldsmeta, bcval);
 }
 
 // clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel
