@@ -377,6 +377,37 @@ def test_two_step_fusion_slab_protocol(shape, walls_cls, steps):
         ctx.set_option("overlap", 1)
 
 
+@pytest.mark.parametrize("walls_cls", [HalfwayBounceBackBC, FullwayBounceBackBC])
+@pytest.mark.parametrize("steps", [4, 5])
+def test_two_step_clean_items_on_the_slack_ring(walls_cls, steps):
+    """A lid-driven cavity cut into thin end segments and clean middle segments (fuse2_xseg = 4 at nx = 48: planes 0-8, 8-24, 24-40,
+    40-48): the middle segments of the interior tile columns carry no boundary cell and run the BC-free body on its slack LDS ring
+    (one barrier per plane) inside the BC kernel, next to hull items on the 43-plane ring — bit for bit against the oracle, and the
+    same with the clean flags off."""
+    shape, omega = (48, 24, 192), 1.4
+    grid, bcs, lat, obcs = hip_cavity_3d(shape, walls_cls)
+    ctx = get_context()
+    f_np = orc.perturbed_init(shape, lat, seed=41)
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    exp = orc.run(f_np, o_bm, o_mm, obcs, omega, lat, steps)
+    try:
+        ctx.set_option("fuse2", 2)
+        ctx.set_option("fuse2_xseg", 4)
+        for clean in (1, 0):
+            ctx.set_option("fuse2_clean", clean)
+            stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+            f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+            assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+            f_0.assign(f_np)
+            f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+            out = f_0.numpy()
+            assert np.array_equal(out, exp), f"fuse2_clean={clean}: max abs {np.abs(out - exp).max()}"
+    finally:
+        ctx.set_option("fuse2", 1)
+        ctx.set_option("fuse2_xseg", 0)
+        ctx.set_option("fuse2_clean", 1)
+
+
 @pytest.mark.parametrize("faces", [("front", "back"), ("front",), ("bottom", "top")])
 def test_two_step_y_wall_redirect_regression(faces):
     """Regression for the memory fault of round 1 (gpurun_out/f.err, fixed by commit 2111f4e): halfway walls on the y
