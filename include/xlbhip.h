@@ -78,7 +78,10 @@ enum {
    * mesh masker produced (xlbhip_stepper_set_bc_distances) */
   XLBHIP_BC_HYBRID_BB_REGULARIZED = 10,  /* interpolated bounce-back + regularisation (bc_hybrid.py:256-290) */
   XLBHIP_BC_HYBRID_BB_GRADS = 11,        /* interpolated bounce-back + Grad's approximation (:292-326) */
-  XLBHIP_BC_HYBRID_NEQ_REGULARIZED = 12  /* non-equilibrium bounce-back + regularisation (:328-358) */
+  XLBHIP_BC_HYBRID_NEQ_REGULARIZED = 12, /* non-equilibrium bounce-back + regularisation (:328-358) */
+  /* halfway bounce-back whose wall velocity is a per-cell table (xlbhip_stepper_set_bc_profile): the reference's
+     HalfwayBounceBackBC(profile=...) of the kernel backends, bc_halfway_bounce_back.py:144-169 + helper_functions_bc.py:230-250 */
+  XLBHIP_BC_HALFWAY_BB_PROFILE = 13
 };
 
 /* One boundary condition as the stepper sees it.  `values` holds, in COMPUTE

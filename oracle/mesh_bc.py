@@ -230,7 +230,8 @@ def mesh_mask_aabb_close(shape, lat, bc_id, vertices, close_voxels, bc_mask, mis
 
 # ---- HybridBC ------------------------------------------------------------------------------------------------------
 class HybridBC(orc.BC):
-    """Descriptor: kind in HYBRID_KINDS; u_wall = None (no-slip) or the wall velocity; distances = None or the (q, ...)
+    """Descriptor: kind in HYBRID_KINDS; u_wall = None (no-slip), the wall velocity (3,) or a per-cell field (3, nx, ny, nz) — the
+    reference's profile(index), bc_hybrid.py:265; distances = None or the (q, ...)
     array of weights the mesh masker produced (weight of missing direction l sits in slot opp l, bc_hybrid.py:207-214)."""
 
     def __init__(self, kind, bc_id, indices, u_wall=None, distances=None):
@@ -239,6 +240,27 @@ class HybridBC(orc.BC):
         self.kind = kind
         self.u_wall = u_wall
         self.distances = distances
+
+
+class HalfwayProfileBC(orc.BC):
+    """Halfway bounce-back whose wall velocity is a per-cell field (3, nx, ny, nz): the kernel backends' HalfwayBounceBackBC(profile=...),
+    bc_halfway_bounce_back.py:144-169 with moving_wall_fpop_correction (helper_functions_bc.py:230-250)."""
+
+    def __init__(self, bc_id, indices, u_wall):
+        super().__init__(orc.KIND_HALFWAY_BB, bc_id, indices)
+        self.kind = "halfway_bounce_back_profile"
+        self.u_wall = u_wall
+
+
+def apply_halfway_profile(bc, f_pre, f_post, bc_mask, missing_mask, lat):
+    T = f_post.dtype.type
+    uw = np.asarray(bc.u_wall, np.float64).astype(T)
+    boundary = bc_mask == bc.id
+    out = f_post.copy()
+    for l in range(lat.q):
+        cond = np.logical_and(missing_mask[l].astype(bool), boundary[0])
+        out[l] = np.where(cond, f_pre[lat.opp[l]] + _moving_term(lat, uw, l, T), f_post[l])
+    return out
 
 
 def _qi(lat, T):
@@ -296,7 +318,8 @@ def apply_hybrid(bc, f_pre, f_post, bc_mask, missing_mask, lat, policy):
         rho, u = orc.macroscopic(f_pre, lat)
         feq = orc.equilibrium(rho, u, lat, T)
         if moving:
-            feq_wall = orc.equilibrium(rho, np.broadcast_to(uw.reshape((lat.d,) + (1,) * lat.d), u.shape).astype(T), lat, T)
+            uw_field = uw if uw.ndim > 1 else np.broadcast_to(uw.reshape((lat.d,) + (1,) * lat.d), u.shape)
+            feq_wall = orc.equilibrium(rho, np.ascontiguousarray(uw_field).astype(T), lat, T)
         for l in range(q):
             wl = wgt[opp[l]] if use_dist else T(0.5)
             fneq = f_pre[opp[l]] - feq[opp[l]]
@@ -347,13 +370,15 @@ def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collisi
     for bc in bcs:
         if bc.kind in HYBRID_KINDS:
             post = apply_hybrid(bc, F0, post, bc_mask, missing_mask, lat, policy)
+        elif bc.kind == "halfway_bounce_back_profile":
+            post = apply_halfway_profile(bc, F0, post, bc_mask, missing_mask, lat)
         elif bc.step == orc.STEP_STREAMING:
             post = orc.apply_bc(bc, F0, post, bc_mask, missing_mask, lat, policy)
     rho, u = orc.macroscopic(post, lat)
     feq = orc.equilibrium(rho, u, lat, T)
     coll = orc.bgk(post, feq, omega) if collision == "BGK" else orc.kbc(post, feq, omega, lat)
     for bc in bcs:
-        if bc.kind not in HYBRID_KINDS:
+        if bc.kind not in HYBRID_KINDS and bc.kind != "halfway_bounce_back_profile":
             coll = orc.assemble_auxiliary_data(bc, post, coll, bc_mask, missing_mask, lat)
             if bc.step == orc.STEP_COLLISION:
                 coll = orc.apply_bc(bc, post, coll, bc_mask, missing_mask, lat, policy)

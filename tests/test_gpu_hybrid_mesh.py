@@ -156,6 +156,110 @@ def test_hybrid_bc_on_a_mesh_with_distances_vs_oracle(bc_method, method):
     assert np.array_equal(out[fluid], exp[fluid])
 
 
+@pytest.mark.parametrize("bc_method", list(KINDS))
+@pytest.mark.parametrize("with_dist", [False, True])
+@pytest.mark.parametrize("lattice,policy", [("D3Q19", "FP32FP32"), ("D3Q27", "FP64FP32")])
+def test_hybrid_bc_wall_velocity_profile_vs_oracle(bc_method, with_dist, lattice, policy):
+    """A ROTATING mesh sphere (the reference's examples/cfd/rotating_sphere_3d.py:114-146): HybridBC(profile=...) with the wall velocity
+    omega x (r - centre) per boundary cell — the reference evaluates profile(index) in the kernel (bc_hybrid.py:265), here the stepper
+    evaluates the callable at the BC's cells and the kernel reads a sparse table.  Masks and 8 steps vs the oracle, bit for bit."""
+    vs, pp = init_hip(lattice, policy)
+    lat = orc.Lattice(lattice)
+    grid = grid_factory(SHAPE)
+    verts = icosphere(CENTER, RADIUS, 1)
+    rot = np.array([0.0, 0.004, -0.002])
+    seen = {}
+
+    def profile(cells):
+        seen["n"] = cells.shape[1]
+        r = cells.astype(np.float64) - np.asarray(CENTER).reshape(3, 1)
+        return np.cross(rot.reshape(1, 3), r.T).T
+
+    b_s = HybridBC(bc_method, profile=profile, mesh_vertices=verts, voxelization_method=method_of("RAY"), use_mesh_distance=with_dist)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[b_s], collision_type="KBC" if lattice == "D3Q27" else "BGK")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    z1, zq = np.zeros((1,) + SHAPE, np.uint8), np.zeros((lat.q,) + SHAPE, bool)
+    res = mb.mesh_mask_ray(SHAPE, lat, b_s.id, verts, z1, zq, np.zeros((lat.q,) + SHAPE, np.float32) if with_dist else None)
+    o_bm, o_mm = res[0], res[1]
+    o_d = res[2] if with_dist else None
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    assert seen["n"] == int((o_bm[0] == b_s.id).sum()) > 0
+    # the same field of wall velocities for the oracle (values only matter at the BC's cells)
+    idx = np.stack(np.meshgrid(*[np.arange(n) for n in SHAPE], indexing="ij")).reshape(3, -1)
+    uw = profile(idx).reshape((3,) + SHAPE)
+    o_s = mb.HybridBC(KINDS[bc_method], b_s.id, None, u_wall=uw, distances=o_d)
+    f_np = orc.perturbed_init(SHAPE, lat, policy, seed=47, amp_rho=0.01, amp_u=0.02)
+    f_0.assign(f_np)
+    steps, omega = 8, 1.4
+    ctx = __import__("xlb_amd.default_config", fromlist=["get_context"]).get_context()
+    try:
+        ctx.set_option("exact_math", 1)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+        out = f_0.numpy()
+    finally:
+        ctx.set_option("exact_math", 0)
+    with np.errstate(all="ignore"):
+        exp = mb.run(f_np, o_bm, o_mm, [o_s], omega, lat, steps, policy, "KBC" if lattice == "D3Q27" else "BGK")
+    fluid = np.broadcast_to(o_bm != BC_SOLID, out.shape)
+    assert np.isfinite(out[fluid]).all()
+    assert np.array_equal(out[fluid], exp[fluid])
+    with pytest.raises(Exception, match="runs inside the stepper"):
+        b_s(f_0, f_1, bc_mask, missing_mask)  # the stand-alone operator call has no table to read
+
+
+@pytest.mark.parametrize("case", ["mesh_3d", "indices_2d"])
+def test_halfway_bc_wall_velocity_profile_vs_oracle(case):
+    """HalfwayBounceBackBC(profile=...) (the alternative the reference's rotating-sphere driver names, rotating_sphere_3d.py:137): the wall
+    velocity omega x (r - centre) per boundary cell, on a RAY-voxelised mesh sphere in 3-D and on an index-built cylinder in 2-D."""
+    if case == "mesh_3d":
+        vs, pp = init_hip("D3Q19")
+        lat, shape = orc.Lattice("D3Q19"), SHAPE
+        grid = grid_factory(shape)
+        rot, ctr = np.array([0.003, 0.0, -0.004]), np.asarray(CENTER)
+
+        def profile(cells):
+            return np.cross(rot.reshape(1, 3), (cells.astype(np.float64) - ctr.reshape(3, 1)).T).T
+
+        bc = HalfwayBounceBackBC(profile=profile, mesh_vertices=icosphere(CENTER, RADIUS, 1), voxelization_method=method_of("RAY"))
+        z1, zq = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+        o_bm, o_mm = mb.mesh_mask_ray(shape, lat, bc.id, icosphere(CENTER, RADIUS, 1), z1, zq, None)[:2]
+    else:
+        vs, pp = init_hip("D2Q9")
+        lat, shape = orc.Lattice("D2Q9"), (24, 20)
+        grid = grid_factory(shape)
+        ctr, w = np.array([11.3, 9.6]), 0.005
+        yy, zz = np.meshgrid(np.arange(shape[0]), np.arange(shape[1]), indexing="ij")
+        inside = (yy - ctr[0]) ** 2 + (zz - ctr[1]) ** 2 <= 4.2**2
+        idx = [yy[inside].tolist(), zz[inside].tolist()]
+
+        def profile(cells):  # rotation about the axis normal to the plane: u = w (-(z - cz), (y - cy))
+            r = cells.astype(np.float64) - ctr.reshape(2, 1)
+            return np.stack([-w * r[1], w * r[0]])
+
+        bc = HalfwayBounceBackBC(profile=profile, indices=idx)
+        o_bm, o_mm = orc.build_masks(shape, lat, [orc.BC(orc.KIND_HALFWAY_BB, bc.id, idx)])
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[bc])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert np.array_equal(bc_mask.numpy(), o_bm) and np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    allc = np.stack(np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")).reshape(lat.d, -1)
+    uw = profile(allc).reshape((lat.d,) + shape)
+    o_b = mb.HalfwayProfileBC(bc.id, None, uw)
+    f_np = orc.perturbed_init(shape, lat, seed=53, amp_rho=0.01, amp_u=0.02)
+    f_0.assign(f_np)
+    steps, omega = 9, 1.5
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+    with np.errstate(all="ignore"):
+        exp = mb.run(f_np, o_bm, o_mm, [o_b], omega, lat, steps)
+    out = f_0.numpy()
+    fluid = np.broadcast_to(o_bm != BC_SOLID, out.shape)
+    assert np.isfinite(out[fluid]).all()
+    assert np.array_equal(out[fluid], exp[fluid])
+    # the wall really moves: the same run with a no-slip wall differs
+    with np.errstate(all="ignore"):
+        still = mb.run(f_np, o_bm, o_mm, [mb.HalfwayProfileBC(bc.id, None, np.zeros_like(uw))], omega, lat, steps)
+    assert not np.array_equal(still[fluid], exp[fluid])
+
+
 def test_hybrid_bc_standalone_operator_vs_oracle():
     """bc(f_pre, f_post, bc_mask, missing_mask) -> f_post (boundary_condition.py:146-180), without mesh distances."""
     vs, pp = init_hip("D3Q19")

@@ -22,6 +22,7 @@ BC_EQUILIBRIUM, BC_HALFWAY_BB, BC_FULLWAY_BB, BC_DO_NOTHING = 1, 2, 3, 4
 BC_ZOUHE_VELOCITY, BC_ZOUHE_PRESSURE, BC_REGULARIZED_VELOCITY, BC_REGULARIZED_PRESSURE = 5, 6, 7, 8
 BC_EXTRAPOLATION_OUTFLOW = 9
 BC_HYBRID_BB_REGULARIZED, BC_HYBRID_BB_GRADS, BC_HYBRID_NEQ_REGULARIZED = 10, 11, 12
+BC_HALFWAY_BB_PROFILE = 13
 MESH_AABB, MESH_RAY, MESH_AABB_CLOSE, MESH_WINDING = 1, 2, 3, 4
 UNIQUE_ID_BYTES = 128
 

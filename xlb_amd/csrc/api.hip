@@ -606,7 +606,7 @@ int xlbhip_apply_bc_profile(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc
   XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_post), "bc: bad bc_mask field");
   XLB_REQUIRE(same_grid(f_pre, f_post), "bc: grids differ");
   XLB_REQUIRE(bc->id >= 1 && bc->id <= 255, "bc id %d out of range", bc->id);
-  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d", bc->kind);
+  XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d (wall-velocity tables live in the stepper)", bc->kind);
   XLB_REQUIRE(bc->kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || (lattice_d(lattice) == 3 && bc->values[4] == 0.0),
               "HybridBC as a stand-alone operator: 3-D lattices, without mesh distances (those live in the stepper: xlbhip_stepper_set_bc_distances)");
   if (bc->kind == XLBHIP_BC_HALFWAY_BB || bc->kind >= XLBHIP_BC_ZOUHE_VELOCITY)
@@ -1508,8 +1508,9 @@ int xlbhip_stepper_create(xlbhip_ctx* c, int lattice, int collision, int cdt, in
   for (int i = 0; i < n_bc; ++i) {
     const xlbhip_bc_desc& b = bcs[i];
     XLB_REQUIRE(b.id >= 1 && b.id <= 255, "bc id %d out of range 1..255", b.id);
-    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d", b.kind);
-    XLB_REQUIRE(b.kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || lattice_d(lattice) == 3, "This BC is not implemented in 2D!");  // bc_hybrid.py:119-120
+    XLB_REQUIRE(b.kind >= XLBHIP_BC_EQUILIBRIUM && b.kind <= XLBHIP_BC_HALFWAY_BB_PROFILE, "unknown bc kind %d", b.kind);
+    XLB_REQUIRE(b.kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || b.kind > XLBHIP_BC_HYBRID_NEQ_REGULARIZED || lattice_d(lattice) == 3,
+                "This BC is not implemented in 2D!");  // bc_hybrid.py:119-120
     if (b.kind == XLBHIP_BC_EXTRAPOLATION_OUTFLOW) has_outflow = true;
     if (b.kind >= XLBHIP_BC_ZOUHE_VELOCITY || b.kind == XLBHIP_BC_DO_NOTHING) has_edge_kinds = true;
     XLB_REQUIRE(kind[b.id] == 0, "bc id %d used twice", b.id);

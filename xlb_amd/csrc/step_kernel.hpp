@@ -339,6 +339,29 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
               val = a.prof_vals + 3 * (size_t)prof_find(a.prof_keys, a.n_prof, (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k);
             zouhe_cell<L, T>(f[k], m, val, kind == XLBHIP_BC_ZOUHE_VELOCITY || kind == XLBHIP_BC_REGULARIZED_VELOCITY,
                              kind >= XLBHIP_BC_REGULARIZED_VELOCITY);
+          } else if (kind == XLBHIP_BC_HALFWAY_BB_PROFILE) {
+            // halfway bounce-back with this cell's wall velocity from the profile table: missing & boundary ->
+            // f_pre[opp] + 6 w_l (c_l . u_wall), the components summed in order (helper_functions_bc.py:230-250)
+            const unsigned m = ld(a.miss + (size_t)Xs[1] * plane_cells, opaque((cell_in_plane + (unsigned)k) * 4u));
+            const unsigned cbo = opaque(cb);
+            T uw[3] = {T(0), T(0), T(0)};
+            if (a.n_prof > 0) {
+              const T* pv = a.prof_vals + 3 * (size_t)prof_find(a.prof_keys, a.n_prof, (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k);
+              uw[0] = pv[0];
+              uw[1] = pv[1];
+              uw[2] = pv[2];
+            }
+            static_for<Q>([&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              const S* own = a.src + (size_t)opp<L>(l) * a.plane_stride + (size_t)Xs[1] * plane_cells;  // uniform
+              T cu = T(0.0);
+              static_for<3>([&](auto ac) {
+                constexpr int ax = decltype(ac)::value;
+                if constexpr (L::c(ax, l) == 1) cu = cu + uw[ax];
+                if constexpr (L::c(ax, l) == -1) cu = cu - uw[ax];
+              });
+              if ((m >> l) & 1u) f[k][l] = to_compute<T, S>(ld(own, cbo)) + cu * (T(6.0) * T(L::w(l)));
+            });
           } else if (kind >= XLBHIP_BC_HYBRID_BB_REGULARIZED && kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED) {
             if constexpr (L::D == 3) {
               // bc_hybrid.py:254-358: own pre-streaming populations, missing bits, wall velocity and (optionally) the
@@ -353,12 +376,20 @@ __global__ void __launch_bounds__(VEC == 1 ? XLB_LB1 : 256) k_step(const StepArg
                 pre[l] = to_compute<T, S>(ld(own, cbo));
               });
               const float* wgt = nullptr;
+              const unsigned key = (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k;
               if (val[4] != T(0) && a.n_dist > 0) {
-                const unsigned key = (unsigned)Xs[1] * (unsigned)plane_cells + cell_in_plane + (unsigned)k;
                 const int slot = prof_find(a.dist_keys, a.n_dist, key);
                 if (a.dist_keys[slot] == key) wgt = a.dist_vals + (size_t)slot * Q;
               }
-              hybrid_cell<L, T>(f[k], pre, m, wgt, val, (int)kind - XLBHIP_BC_HYBRID_BB_REGULARIZED);
+              // wall velocity: the BC's constant, or this cell's entry of the profile table (bc_hybrid.py:265: profile(index))
+              T uw[5] = {val[0], val[1], val[2], val[3], val[4]};
+              if (val[PROF_FLAG] != T(0) && a.n_prof > 0) {
+                const T* pv = a.prof_vals + 3 * (size_t)prof_find(a.prof_keys, a.n_prof, key);
+                uw[0] = pv[0];
+                uw[1] = pv[1];
+                uw[2] = pv[2];
+              }
+              hybrid_cell<L, T>(f[k], pre, m, wgt, uw, (int)kind - XLBHIP_BC_HYBRID_BB_REGULARIZED);
             }
           }
         }

@@ -171,9 +171,17 @@ class HalfwayBounceBackBC(BoundaryCondition):
         if profile is not None:
             if prescribed_value is not None:
                 raise ValueError("Cannot specify both profile and prescribed_value")
-            raise NotImplementedError("callable wall-velocity profiles are out of scope of the HIP backend; use prescribed_value")
-        self.needs_moving_wall_treatment = prescribed_value is not None
-        if prescribed_value is None:
+            if not callable(profile):
+                raise ValueError("profile must be a callable: cell indices (d, n) -> wall velocities (d, n)")
+            # a time-independent wall velocity per boundary cell (the reference's profile(index) Warp function,
+            # bc_halfway_bounce_back.py:76-96): evaluated by the stepper at this BC's cells, a sparse table for the kernel
+            self.hip_kind = _lib.BC_HALFWAY_BB_PROFILE
+        self.profile = profile
+        self._profile_table_data = None
+        self.needs_moving_wall_treatment = prescribed_value is not None or profile is not None
+        if prescribed_value is None and profile is not None:
+            prescribed_value = [0] * self.velocity_set.d
+        elif prescribed_value is None:
             print(f"WARNING! Assuming no-slip condition for BC type = {self.__class__.__name__}!")
             prescribed_value = [0] * self.velocity_set.d
         if not isinstance(prescribed_value, (tuple, list, np.ndarray)):
@@ -182,11 +190,24 @@ class HalfwayBounceBackBC(BoundaryCondition):
         if self.prescribed_value.shape != (self.velocity_set.d,):
             raise ValueError(f"prescribed_value must have {self.velocity_set.d} components")
 
+    def _evaluate_profile(self, cells, storage_keys):
+        """Called by the stepper with this BC's cells ((3, n) global indices, x first) and their storage cell indices."""
+        d = self.velocity_set.d
+        vals = np.asarray(self.profile(cells[3 - d :]), dtype=np.float64)
+        if vals.shape != (d, cells.shape[1]):
+            raise ValueError(f"profile(indices) must return an array of shape (d, n) = {(d, cells.shape[1])}, got {vals.shape}")
+        v3 = np.zeros((cells.shape[1], 3))
+        v3[:, 3 - d :] = vals.astype(self.compute_dtype).astype(np.float64).T  # internal 3-component form
+        self._profile_table_data = (np.asarray(storage_keys, dtype=np.uint32), v3)
+
+    def _profile_table(self, grid):
+        return self._profile_table_data
+
     def _hip_values(self):
         vs = self.velocity_set
         T, S = self.compute_dtype, self.store_dtype
         out = np.zeros(vs.q, dtype=T)
-        if not self.needs_moving_wall_treatment:
+        if not self.needs_moving_wall_treatment or self.profile is not None:
             return out.astype(np.float64)
         # bc_halfway_bounce_back.py:97-102,124-128: u_wall in STORE precision, 6 * (w * (c . u_wall))
         uw = self.prescribed_value.astype(S)
@@ -200,6 +221,8 @@ class HalfwayBounceBackBC(BoundaryCondition):
 
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        if self.profile is not None:
+            raise NotImplementedError("a HalfwayBounceBackBC with a wall-velocity profile runs inside the stepper (its per-cell table lives there)")
         return self._apply(f_pre, f_post, bc_mask, missing_mask)
 
 
@@ -415,10 +438,14 @@ class HybridBC(BoundaryCondition):
     * ``"bounceback_grads"``        interpolated bounce-back + Grad's approximation of the missing populations,
     * ``"nonequilibrium_regularized"``  Tao et al.'s non-equilibrium bounce-back + regularisation.
 
-    ``prescribed_value`` = constant wall velocity (moving-wall treatment), none = no-slip.  ``use_mesh_distance`` needs
+    ``prescribed_value`` = constant wall velocity (moving-wall treatment), none = no-slip; ``profile`` = a time-independent wall velocity
+    per boundary cell (the reference's ``profile(index)`` Warp function, bc_hybrid.py:163-172, 265 — e.g. a rotating body,
+    examples/cfd/rotating_sphere_3d.py:114-131): here a Python callable that takes the (3, n) integer array of this BC's cell indices and
+    returns the (3, n) velocities; the stepper evaluates it once the masks exist and hands the values to the kernel as a sparse
+    per-cell table.  ``use_mesh_distance`` needs
     ``mesh_vertices`` and a voxelisation method with distances (RAY, WINDING, AABB_CLOSE): the interpolation then uses the
-    fractional distance to the surface along every cut link instead of the halfway assumption.  Warp ``@wp.func``
-    profiles are out of scope (no Warp here)."""
+    fractional distance to the surface along every cut link instead of the halfway assumption.  Time-dependent profiles
+    (``profile(index, timestep)``) are out of scope."""
 
     _kinds = {"bounceback_regularized": _lib.BC_HYBRID_BB_REGULARIZED, "bounceback_grads": _lib.BC_HYBRID_BB_GRADS,
               "nonequilibrium_regularized": _lib.BC_HYBRID_NEQ_REGULARIZED}
@@ -437,9 +464,14 @@ class HybridBC(BoundaryCondition):
         if profile is not None:
             if prescribed_value is not None:
                 raise AssertionError("Cannot specify both profile and prescribed_value")
-            raise NotImplementedError("wall-velocity profiles are Warp functions in the reference; the HIP backend takes prescribed_value")
-        self.needs_moving_wall_treatment = prescribed_value is not None
-        if prescribed_value is None:
+            if not callable(profile):
+                raise ValueError("profile must be a callable: cell indices (3, n) -> wall velocities (3, n)")
+        self.profile = profile
+        self._profile_table_data = None  # (storage cells, (n, 3) values): the stepper evaluates the profile at this BC's cells
+        self.needs_moving_wall_treatment = prescribed_value is not None or profile is not None
+        if prescribed_value is None and profile is not None:
+            prescribed_value = [0, 0, 0]  # (placeholder: every cell of this BC reads its velocity from the table)
+        elif prescribed_value is None:
             print(f"WARNING! Assuming no-slip condition for BC type = {self.__class__.__name__}_{self.bc_method}!")
             prescribed_value = [0, 0, 0]
         if not isinstance(prescribed_value, (tuple, list, np.ndarray)):
@@ -457,6 +489,17 @@ class HybridBC(BoundaryCondition):
             self.needs_padding = True
         self._distance_table = None
 
+    def _evaluate_profile(self, cells, storage_keys):
+        """Called by the stepper with this BC's cells ((3, n) global indices) and their storage cell indices."""
+        vals = np.asarray(self.profile(cells), dtype=np.float64)
+        if vals.shape != (3, cells.shape[1]):
+            raise ValueError(f"profile(indices) must return an array of shape (3, n) = {(3, cells.shape[1])}, got {vals.shape}")
+        vals = vals.astype(self.compute_dtype).astype(np.float64)
+        self._profile_table_data = (np.asarray(storage_keys, dtype=np.uint32), np.ascontiguousarray(vals.T))
+
+    def _profile_table(self, grid):
+        return self._profile_table_data
+
     def _hip_values(self):
         out = np.zeros(self.velocity_set.q)
         out[:3] = self.prescribed_value.astype(self.compute_dtype)
@@ -466,4 +509,6 @@ class HybridBC(BoundaryCondition):
 
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_pre, f_post, bc_mask, missing_mask):
+        if self.profile is not None:
+            raise NotImplementedError("a HybridBC with a wall-velocity profile runs inside the stepper (its per-cell table lives there)")
         return self._apply(f_pre, f_post, bc_mask, missing_mask)

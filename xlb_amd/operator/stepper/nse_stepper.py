@@ -135,6 +135,18 @@ class IncompressibleNavierStokesStepper(Stepper):
 
             mesh_masker = mesh_masker_for(getattr(bc, "voxelization_method", None), self.velocity_set, self.precision_policy, self.compute_backend)
             f_1, bc_mask, missing_mask = mesh_masker(bc, f_1, bc_mask, missing_mask)
+        # wall-velocity profiles (HybridBC(profile=...), bc_hybrid.py:163-172): evaluated at the BC's cells, known only now
+        with_profile = [bc for bc in boundary_conditions if callable(getattr(bc, "_evaluate_profile", None)) and getattr(bc, "profile", None)]
+        if with_profile:
+            if bc_mask.halo != 0:
+                raise NotImplementedError("wall-velocity profiles need fields without ghost planes (single rank)")
+            ids = bc_mask.numpy()[0]
+            if ids.ndim == 2:
+                ids = ids[None]
+            for bc in with_profile:
+                cells = np.argwhere(ids == bc.id).T  # (3, n), ascending storage order
+                keys = (cells[0] * ids.shape[1] + cells[1]) * ids.shape[2] + cells[2]
+                bc._evaluate_profile(cells, keys)
         return f_1, bc_mask, missing_mask
 
     @Operator.register_backend(ComputeBackend.HIP)
