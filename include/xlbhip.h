@@ -247,6 +247,11 @@ int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const
  * in f_1 and recovers them every step (bc_hybrid.py:207-214, nse_stepper.py:398-425); here they live in a sorted table
  * that the boundary lanes of the step kernel search.  Calls accumulate (one per mesh BC). */
 int xlbhip_stepper_set_bc_distances(xlbhip_stepper* s, int64_t n, const uint32_t* storage_cells, const float* weights);
+/* MomentumTransfer for a HybridBC or a profile wall of this stepper (the kernel backends' path, force/momentum_transfer.py:225-262 with
+ * FetchPopulations :75-92): f_post_stream = that BC applied to (own populations of f_0, populations pulled from f_0) with the stepper's
+ * wall-distance and wall-velocity tables; force[3] in the internal 3-component form.  Fields without ghost planes. */
+int xlbhip_stepper_momentum_transfer(xlbhip_stepper* s, int bc_id, const xlbhip_field* f_0, const xlbhip_field* bc_mask, const xlbhip_field* missing_mask,
+                                     double force[3]);
 /* ForcedCollision with the exact-difference scheme (forced_collision.py:44-50, exact_difference_force.py:61-83):
  * force[3] in the internal 3-component form; NULL switches forcing off */
 int xlbhip_stepper_set_force(xlbhip_stepper* s, const double* force);

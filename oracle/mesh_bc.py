@@ -362,6 +362,24 @@ def apply_hybrid(bc, f_pre, f_post, bc_mask, missing_mask, lat, policy):
     return np.where(np.broadcast_to(boundary, out.shape), out, f_post)
 
 
+def momentum_transfer(f_0, bc, bc_mask, missing_mask, lat, policy="FP32FP32"):
+    """MomentumTransfer for a HybridBC / HalfwayProfileBC descriptor: force/momentum_transfer.py:225-262 with FetchPopulations (:75-92) —
+    f_post_stream = the BC applied to (f_0, stream(f_0)); the sum over the grid in NumPy's order (unpinned in the reference: atomics)."""
+    T = orc.compute_dtype(policy)
+    f_pc = f_0.astype(T)
+    f_ps = orc.stream(f_pc, lat)
+    if bc.kind in HYBRID_KINDS:
+        f_ps = apply_hybrid(bc, f_pc, f_ps, bc_mask, missing_mask, lat, policy)
+    else:
+        f_ps = apply_halfway_profile(bc, f_pc, f_ps, bc_mask, missing_mask, lat)
+    mm = missing_mask.astype(bool)
+    boundary = np.broadcast_to(bc_mask == bc.id, mm.shape)
+    is_edge = np.logical_and(boundary, ~mm[0])
+    phi = np.where(np.logical_and(mm, is_edge), f_pc[lat.opp] + f_ps, T(0.0))
+    force = np.tensordot(lat.c[:, lat.opp].astype(T), phi, axes=(-1, 0))
+    return force.reshape(lat.d, -1).sum(axis=1, dtype=np.float64).astype(T)
+
+
 def step(f_0, bc_mask, missing_mask, bcs, omega, lat, policy="FP32FP32", collision="BGK"):
     """orc.step with HybridBC descriptors allowed in the list (streaming step, list order; nse_stepper.py:237-282)."""
     T, S = orc.compute_dtype(policy), orc.store_dtype(policy)

@@ -203,6 +203,16 @@ def test_hybrid_bc_wall_velocity_profile_vs_oracle(bc_method, with_dist, lattice
     fluid = np.broadcast_to(o_bm != BC_SOLID, out.shape)
     assert np.isfinite(out[fluid]).all()
     assert np.array_equal(out[fluid], exp[fluid])
+    # the force on the sphere (MomentumTransfer through the stepper's distance / velocity tables) vs the oracle; the per-cell terms are
+    # the same arithmetic, the grid sum's order is not (atomics in the reference as well)
+    from xlb_amd.operator.force import MomentumTransfer
+
+    force = MomentumTransfer(b_s)(f_0, f_1, bc_mask, missing_mask)
+    with np.errstate(all="ignore"):
+        fexp = mb.momentum_transfer(np.where(fluid, out, 0).astype(out.dtype), o_s, o_bm, o_mm, lat, policy)
+    tol = 2e-5 if policy == "FP32FP32" else 1e-11
+    assert force.shape == (3,) and np.allclose(force, fexp, rtol=tol, atol=tol * np.abs(fexp).max()), (force, fexp)
+    assert np.abs(fexp).max() > 0
     with pytest.raises(Exception, match="runs inside the stepper"):
         b_s(f_0, f_1, bc_mask, missing_mask)  # the stand-alone operator call has no table to read
 
@@ -258,6 +268,12 @@ def test_halfway_bc_wall_velocity_profile_vs_oracle(case):
     with np.errstate(all="ignore"):
         still = mb.run(f_np, o_bm, o_mm, [mb.HalfwayProfileBC(bc.id, None, np.zeros_like(uw))], omega, lat, steps)
     assert not np.array_equal(still[fluid], exp[fluid])
+    from xlb_amd.operator.force import MomentumTransfer
+
+    force = MomentumTransfer(bc)(f_0, f_1, bc_mask, missing_mask)
+    with np.errstate(all="ignore"):
+        fexp = mb.momentum_transfer(np.where(fluid, out, 0).astype(out.dtype), o_b, o_bm, o_mm, lat)
+    assert force.shape == (lat.d,) and np.allclose(force, fexp, rtol=2e-5, atol=2e-5 * np.abs(fexp).max()), (force, fexp)
 
 
 def test_hybrid_bc_standalone_operator_vs_oracle():

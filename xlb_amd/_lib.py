@@ -73,6 +73,7 @@ SIGNATURES = {
     "xlbhip_mesh_mask": [_p, _i, _i, _i, _i64, _p, _i, _p, _p, _p],
     "xlbhip_field_gather": [_p, _i64, _p, _p, C.c_size_t],
     "xlbhip_stepper_set_bc_distances": [_p, _i64, _p, _p],
+    "xlbhip_stepper_momentum_transfer": [_p, _i, _p, _p, _p, C.POINTER(C.c_double)],
     "xlbhip_grid_to_point": [_p, _p, _i64, _p, _p],
     "xlbhip_momentum_transfer": [_p, _i, _i, C.POINTER(BcDesc), _p, _p, _p, C.POINTER(C.c_double)],
     "xlbhip_stepper_set_bc_profile": [_p, _i, _i64, _p, _p],
@@ -476,6 +477,12 @@ class Stepper:
         w = np.ascontiguousarray(weights, dtype=np.float32)
         assert w.ndim == 2 and k.shape[0] == w.shape[0]
         check(load().xlbhip_stepper_set_bc_distances(self._h, int(k.shape[0]), k.ctypes.data, w.ctypes.data))
+
+    def momentum_transfer(self, bc_id, f_0, bc_mask, missing_mask):
+        """Force (3,) on the solid behind a HybridBC / profile wall of this stepper (its distance and velocity tables)."""
+        out = (C.c_double * 3)()
+        check(load().xlbhip_stepper_momentum_transfer(self._h, int(bc_id), f_0.handle, _h(bc_mask), _h(missing_mask), out))
+        return np.array(out[:], dtype=np.float64)
 
     def set_smagorinsky(self, coef):
         check(load().xlbhip_stepper_set_smagorinsky(self._h, float(coef)))

@@ -1600,6 +1600,49 @@ int xlbhip_stepper_set_bc_profile(xlbhip_stepper* s, int bc_id, int64_t n, const
   return 0;
 }
 
+int xlbhip_stepper_momentum_transfer(xlbhip_stepper* s, int bc_id, const xlbhip_field* f_0, const xlbhip_field* bcm, const xlbhip_field* miss,
+                                     double force_out[3]) {
+  XLB_REQUIRE(s && force_out && bc_id >= 1 && bc_id <= 255, "bad argument");
+  xlbhip_ctx* c = s->ctx;
+  XLB_CHECK_POP(f_0, s->lattice, "momentum_transfer(f_0)");
+  XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_0) && bcm->halo == f_0->halo, "momentum_transfer: bad bc_mask field");
+  XLB_REQUIRE(miss && miss->dtype == XLBHIP_MISSING && same_grid(miss, f_0) && miss->halo == f_0->halo, "momentum_transfer: needs the missing_mask field");
+  XLB_REQUIRE(f_0->halo == 0, "momentum_transfer through the stepper's tables: fields without ghost planes (mesh / profile BCs live on one rank)");
+  uint8_t kind = 0;
+  XLB_HIP(hipSetDevice(c->device));
+  XLB_HIP(hipMemcpy(&kind, s->tab_kind + bc_id, 1, hipMemcpyDeviceToHost));
+  XLB_REQUIRE((kind >= XLBHIP_BC_HYBRID_BB_REGULARIZED && kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED) || kind == XLBHIP_BC_HALFWAY_BB_PROFILE,
+              "momentum_transfer through the stepper: bc %d is of kind %d (HybridBC / profile walls; plain walls use xlbhip_momentum_transfer)", bc_id,
+              (int)kind);
+  double* dforce = nullptr;
+  XLB_HIP(hipMalloc(&dforce, 3 * sizeof(double)));
+  XLB_HIP(hipMemsetAsync(dforce, 0, 3 * sizeof(double), c->stream));
+  const size_t n = f_0->cells();
+  int rc = by_lattice(s->lattice, [&](auto L) {
+    using LL = decltype(L);
+    if (s->cdt == XLBHIP_F32)
+      hipLaunchKernelGGL((k_momentum_transfer_tab<LL, float>), blocks_for(n), 256, 0, c->stream, view(f_0), view(bcm), view(miss), dims(f_0), bc_id,
+                         s->tab_kind, static_cast<const float*>(s->tab_values), s->prof_keys, static_cast<const float*>(s->prof_vals), s->n_prof,
+                         s->dist_keys, s->dist_vals, s->n_dist, dforce);
+    else
+      hipLaunchKernelGGL((k_momentum_transfer_tab<LL, double>), blocks_for(n), 256, 0, c->stream, view(f_0), view(bcm), view(miss), dims(f_0), bc_id,
+                         s->tab_kind, static_cast<const double*>(s->tab_values), s->prof_keys, static_cast<const double*>(s->prof_vals), s->n_prof,
+                         s->dist_keys, s->dist_vals, s->n_dist, dforce);
+    XLB_HIP(hipGetLastError());
+    return 0;
+  });
+  if (rc == 0) {
+    hipError_t e = hipMemcpyAsync(force_out, dforce, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(dforce);
+      XLB_FAIL("momentum_transfer: %s", hipGetErrorString(e));
+    }
+  }
+  (void)hipFree(dforce);
+  return rc;
+}
+
 int xlbhip_stepper_set_bc_distances(xlbhip_stepper* s, int64_t n, const uint32_t* storage_cells, const float* weights) {
   XLB_REQUIRE(s, "stepper is null");
   XLB_REQUIRE(n == 0 || (storage_cells && weights), "null table");

@@ -350,6 +350,93 @@ __global__ void k_momentum_transfer(FieldView f0, FieldView bc, FieldView miss, 
   if (t < 3 && red[t][0] != 0.0) atomicAdd(force + t, red[t][0]);
 }
 
+// MomentumTransfer for the BCs whose post-stream populations need the stepper's tables (HybridBC: wall distances, wall-velocity
+// profile; halfway bounce-back with a profile) — the kernel backends' path of the reference, force/momentum_transfer.py:225-262 with
+// FetchPopulations (:75-92): f_post_stream = the BC applied to (own populations of f_0, populations pulled from f_0).
+template <class L, class T>
+__global__ void k_momentum_transfer_tab(FieldView f0, FieldView bc, FieldView miss, Dims d, int id, const uint8_t* kind_tab, const T* val_tab,
+                                        const uint32_t* prof_keys, const T* prof_vals, int n_prof, const uint32_t* dist_keys,
+                                        const float* dist_vals, int n_dist, double* force /*[3]*/) {
+  __shared__ double red[3][256];
+  constexpr int Q = L::Q;
+  int x, y, z;
+  T fx = T(0), fy = T(0), fz = T(0);
+  if (cell_of_thread(d, x, y, z)) {
+    const uint8_t b = static_cast<const uint8_t*>(bc.data)[cell_index(bc, d, x, y, z)];
+    if (b == id) {
+      const unsigned m = static_cast<const uint32_t*>(miss.data)[cell_index(miss, d, x, y, z)];
+      if ((m & 1u) == 0u) {
+        const size_t own = cell_index(f0, d, x, y, z);
+        const unsigned key = (unsigned)cell_index(bc, d, x, y, z);
+        const unsigned kind = kind_tab[id];
+        const T* val = val_tab + (unsigned)id * 27u;
+        T pre[Q], ps[Q];
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          pre[l] = load_rt<T>(f0, (size_t)l * f0.plane_stride + own);
+          const int xs = f0.halo ? x - L::c(0, l) : wrap(x - L::c(0, l), d.nx);
+          ps[l] = load_rt<T>(f0, (size_t)l * f0.plane_stride + cell_index(f0, d, xs, wrap(y - L::c(1, l), d.ny), wrap(z - L::c(2, l), d.nz)));
+        });
+        T uw[5] = {val[0], val[1], val[2], val[3], val[4]};
+        if ((kind == XLBHIP_BC_HALFWAY_BB_PROFILE || val[PROF_FLAG] != T(0)) && n_prof > 0) {
+          const T* pv = prof_vals + 3 * (size_t)prof_find(prof_keys, n_prof, key);
+          uw[0] = pv[0];
+          uw[1] = pv[1];
+          uw[2] = pv[2];
+        }
+        if (kind == XLBHIP_BC_HALFWAY_BB_PROFILE) {
+          static_for<Q>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            T cu = T(0.0);
+            static_for<3>([&](auto ac) {
+              constexpr int ax = decltype(ac)::value;
+              if constexpr (L::c(ax, l) == 1) cu = cu + uw[ax];
+              if constexpr (L::c(ax, l) == -1) cu = cu - uw[ax];
+            });
+            if ((m >> l) & 1u) ps[l] = pre[opp<L>(l)] + cu * (T(6.0) * T(L::w(l)));
+          });
+        } else {
+          if constexpr (L::D == 3) {
+            const float* wgt = nullptr;
+            if (val[4] != T(0) && n_dist > 0) {
+              const int slot = prof_find(dist_keys, n_dist, key);
+              if (dist_keys[slot] == key) wgt = dist_vals + (size_t)slot * Q;
+            }
+            hybrid_cell<L, T>(ps, pre, m, wgt, uw, (int)kind - XLBHIP_BC_HYBRID_BB_REGULARIZED);
+          }
+        }
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int o = opp<L>(l);
+          if ((m >> l) & 1u) {
+            const T phi = pre[o] + ps[l];
+            if constexpr (L::c(0, o) == 1) fx = fx + phi;
+            if constexpr (L::c(0, o) == -1) fx = fx - phi;
+            if constexpr (L::c(1, o) == 1) fy = fy + phi;
+            if constexpr (L::c(1, o) == -1) fy = fy - phi;
+            if constexpr (L::c(2, o) == 1) fz = fz + phi;
+            if constexpr (L::c(2, o) == -1) fz = fz - phi;
+          }
+        });
+      }
+    }
+  }
+  const int t = threadIdx.x;
+  red[0][t] = (double)fx;
+  red[1][t] = (double)fy;
+  red[2][t] = (double)fz;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      red[0][t] += red[0][t + s];
+      red[1][t] += red[1][t + s];
+      red[2][t] += red[2][t + s];
+    }
+    __syncthreads();
+  }
+  if (t < 3 && red[t][0] != 0.0) atomicAdd(force + t, red[t][0]);
+}
+
 // ---- GridToPoint (postprocess/grid_to_point.py:28-94): trilinear interpolation of component 0 at arbitrary points ----
 // weights in fp32 from the fp32 point coordinates, as the reference computes them; products and the 8-term sum in its order
 template <class T>

@@ -20,11 +20,22 @@ class MomentumTransfer(Operator):
     def __init__(self, no_slip_bc_instance, velocity_set=None, precision_policy=None, compute_backend=None):
         self.no_slip_bc_instance = no_slip_bc_instance
         super().__init__(velocity_set, precision_policy, compute_backend)
-        if no_slip_bc_instance.hip_kind not in (_lib.BC_HALFWAY_BB, _lib.BC_FULLWAY_BB):
-            raise NotImplementedError("MomentumTransfer supports halfway / fullway bounce-back no-slip BCs on the HIP backend")
+        self._via_stepper = no_slip_bc_instance.hip_kind in (_lib.BC_HYBRID_BB_REGULARIZED, _lib.BC_HYBRID_BB_GRADS, _lib.BC_HYBRID_NEQ_REGULARIZED,
+                                                             _lib.BC_HALFWAY_BB_PROFILE)
+        if not self._via_stepper and no_slip_bc_instance.hip_kind not in (_lib.BC_HALFWAY_BB, _lib.BC_FULLWAY_BB):
+            raise NotImplementedError("MomentumTransfer supports halfway / fullway bounce-back walls and HybridBC on the HIP backend")
 
     @Operator.register_backend(ComputeBackend.HIP)
     def hip_implementation(self, f_0, f_1, bc_mask, missing_mask):
+        if self._via_stepper:
+            # HybridBC / profile walls: the BC's post-stream populations need the wall-distance and wall-velocity tables, which
+            # live in the stepper the BC belongs to (the reference applies bc.warp_functional here, momentum_transfer.py:75-92)
+            owner = getattr(self.no_slip_bc_instance, "_stepper_ref", None)
+            stepper = owner() if owner is not None else None
+            if stepper is None:
+                raise RuntimeError("MomentumTransfer(HybridBC): the BC is not part of a live stepper (prepare_fields / a step come first)")
+            force = stepper._native_stepper().momentum_transfer(self.no_slip_bc_instance.id, f_0, bc_mask, missing_mask)
+            return force[3 - self.velocity_set.d :].astype(self.compute_dtype)
         desc = self.no_slip_bc_instance._hip_descriptor()
         out = (C.c_double * 3)()
         _lib.check(

@@ -94,6 +94,10 @@ class IncompressibleNavierStokesStepper(Stepper):
                                         self._store_code, descs)
             if isinstance(self.collision, SmagorinskyLESBGK):
                 self._native.set_smagorinsky(self.collision.smagorinsky_coef)
+            import weakref
+
+            for bc in self.boundary_conditions:
+                bc._stepper_ref = weakref.ref(self)  # (MomentumTransfer of a HybridBC reads this stepper's tables)
             for bc in self.boundary_conditions:
                 table = bc._profile_table(self.grid) if hasattr(bc, "_profile_table") else None
                 if table is not None:
