@@ -24,3 +24,4 @@ from .operator import boundary_masker as _boundary_masker  # noqa: F401
 from .operator import stepper as _stepper  # noqa: F401
 from . import helper as helper
 from . import distribute as distribute
+from . import utils as utils
