@@ -312,12 +312,15 @@ def main():
 
     # XLB_BENCH_TRANSPORT=host: rehearsal of the N > 1 code path with all ranks on ONE GPU (ghost planes through the
     # host; RCCL refuses two ranks on a device).  Numbers from it are not benchmark results.
-    transport = os.environ.get("XLB_BENCH_TRANSPORT", "rccl")
+    # Default: RCCL, and if its communicator cannot be built (an error, not a hang) every rank falls back to the host transport
+    # and the JSON says so — a slow number with its reason instead of no number.
+    transport = os.environ.get("XLB_BENCH_TRANSPORT", "rccl_or_host")
     # halfway walls on both x faces: no population is ever pulled across them (every such pull is a missing direction
     # that the wall redirects), so the ring is a chain.  Fullway wall cells DO exchange (inert) populations with their
     # periodic images in the reference (roll-based streaming), so that workload keeps the ring.
     periodic_x = args.workload != "cavity_halfway"
     rank, world = xdist.init_process_group(periodic_x=periodic_x, transport=transport)
+    transport = xdist.transport() or transport  # what is actually in use ("host (fallback: ...)" after a failed RCCL set-up)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -425,7 +428,7 @@ def main():
             "baseline_config": "configs[2]" if is_c2 else ("configs[3] (long axis = slowest array axis)" if (is_c3 and world == 8) else
                                                            ("configs[3]'s domain on fewer GPUs" if is_c3 else "other")),
             "decomposition": (f"{world} x-slab(s) of {'/'.join(str(slab_bounds(shape[0], r, world)[1]) for r in range(world))} planes, "
-                              + ("chain" if not periodic_x else "ring") + (" halo over RCCL" if transport == "rccl" else f" halo, REHEARSAL transport {transport}"))
+                              + ("chain" if not periodic_x else "ring") + (" halo over RCCL" if transport == "rccl" else f" halo, NOT over RCCL — transport {transport}"))
                              if world > 1 else "single GPU",
             "per_rank_ms_per_step": per_rank_ms,
         },

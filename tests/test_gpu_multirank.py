@@ -40,6 +40,18 @@ def test_one_rank_real_rccl_self_exchange():
     assert "RCCL_SELF_OK" in out.stdout
 
 
+def test_two_ranks_rccl_or_host_falls_back_together():
+    """transport="rccl_or_host" (bench.py's default): on a one-GPU box RCCL refuses the second rank on the device, every rank hears about
+    it through the rendezvous, all of them switch to the host-staged transport and the run is still bit-identical to the single-domain
+    oracle.  (Where RCCL accepts the device set this is the RCCL run.)"""
+    out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="rccl_or_host")
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert "GPU_SLAB_OK" in out.stdout
+    if "falls back to the host-staged halo transport" in text:
+        assert "RCCL communicator failed" in text
+
+
 def test_two_ranks_rccl():
     out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="rccl", NCCL_DEBUG="WARN")
     text = out.stdout + out.stderr

@@ -10,4 +10,5 @@ from .distribute import (
     all_reduce_min as all_reduce_min,
     all_gather as all_gather,
     shutdown as shutdown,
+    transport as transport,
 )

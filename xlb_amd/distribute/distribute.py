@@ -33,7 +33,12 @@ def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl")
     ``python -m torch.distributed.run`` or by ``bench.py``'s launcher).  Single-process jobs return (0, 1).
 
     ``periodic_x=False``: the global x axis ends in walls, so the ring is a chain — rank 0 and rank N-1
-    exchange nothing (a walled cavity never pulls across that face)."""
+    exchange nothing (a walled cavity never pulls across that face).
+
+    ``transport``: "rccl" (ghost planes over RCCL send / recv; an error if the communicator cannot be built), "host" (through host
+    memory and the rendezvous hub: debugging, several ranks on one GPU), "rccl_or_host" (RCCL, and if building the communicator FAILS on
+    any rank every rank falls back to "host" — decided collectively, said on stderr, reported by ``transport()``; a hang inside RCCL
+    cannot be caught)."""
     rank, world = _env_int("RANK", 0), _env_int("WORLD_SIZE", 1)
     _state["rank"], _state["world"] = rank, world
     if world == 1:
@@ -46,24 +51,53 @@ def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl")
     _state["periodic_x"] = bool(periodic_x)
     if init_device_comm:
         ctx = get_context()  # device = XLB_HIP_DEVICE or LOCAL_RANK (default_config._pick_device)
-        if transport == "rccl":
-            uid = rdv.broadcast(_lib.comm_unique_id() if rank == 0 else None, src=0)
-            ctx.comm_init(rank, world, uid, periodic_x=periodic_x)
-        elif transport == "host":
-            # debugging transport: ghost planes travel through host memory and the rendezvous hub (HostStagedHalo);
-            # lets several ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected")
+        if transport not in ("rccl", "host", "rccl_or_host"):
+            raise ValueError(f"unknown halo transport {transport!r}")
+        _state["transport"] = "host" if transport == "host" else "rccl"
+        if transport != "host":
+            err = None
+            uid = None
+            if rank == 0:
+                try:
+                    uid = _lib.comm_unique_id()
+                except Exception as e:  # noqa: BLE001 (whatever RCCL / the loader raises: the other ranks must hear about it)
+                    err = e
+            uid = rdv.broadcast(uid, src=0)
+            if uid is not None:
+                try:
+                    ctx.comm_init(rank, world, uid, periodic_x=periodic_x)
+                except Exception as e:  # noqa: BLE001
+                    err = e
+            elif err is None:
+                err = RuntimeError("rank 0 could not create the RCCL unique id")
+            reasons = [r for r in rdv.all_gather(None if err is None else f"rank {rank}: {err}") if r]
+            if reasons:
+                if transport == "rccl":
+                    raise err if err is not None else RuntimeError("RCCL communicator failed on another rank: " + reasons[0])
+                import sys
+
+                if rank == 0:
+                    print(f"xlb_amd.distribute: RCCL communicator failed ({reasons[0]}); every rank falls back to the host-staged halo transport",
+                          file=sys.stderr, flush=True)
+                _state["transport"] = "host (fallback: " + reasons[0][:200] + ")"
+        if _state["transport"] != "rccl":
+            # ghost planes travel through host memory and the rendezvous hub (HostStagedHalo): the debugging transport — it lets
+            # several ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected") — and the fallback of "rccl_or_host"
             ctx.rank, ctx.n_ranks = rank, world
             ctx.set_option("external_halo", 1)
-        else:
-            raise ValueError(f"unknown halo transport {transport!r}")
     return rank, world
+
+
+def transport():
+    """The halo transport in use: "rccl", "host", or "host (fallback: <why RCCL failed>)"; None before init_process_group."""
+    return _state.get("transport")
 
 
 def shutdown():
     """Leave the job: close the control-plane sockets (the device communicator dies with the context)."""
     if _state["rdv"] is not None:
         _state["rdv"].close()
-    _state.update(rdv=None, rank=0, world=1)
+    _state.update(rdv=None, rank=0, world=1, transport=None)
 
 
 class HostStagedHalo:
