@@ -170,3 +170,43 @@ def test_d3q27_two_step_kernel_fullsize_tiling():
     f_0.assign(np.tile(tile, (1, reps, reps, reps)))
     f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
     assert np.array_equal(f_0.numpy(), np.tile(exp_tile, (1, reps, reps, reps)))
+
+
+def test_config3_domain_on_one_gpu_matches_the_cube_near_its_walls():
+    """BASELINE configs[3]'s global domain, 4096 x 512 x 512 (1.07 G cells, 81.6 GB per population field: element offsets beyond 2^34,
+    the largest size the path is asked for) on ONE GPU through the two-step kernel, lid-driven cavity with halfway walls.  Information
+    travels one cell per step, so after 6 steps the planes near either x wall are those of the 512^3 cavity, bit for bit — checked on
+    planes of several populations at both ends — and the middle of the long box, which no x wall has reached, repeats along x."""
+    import gc
+
+    from bench import cavity_bcs
+    from xlb_amd.default_config import get_context
+    from xlb_amd.operator.boundary_condition import EquilibriumBC
+
+    n, nx, steps = 512, 4096, 6
+    pops = (0, 2, 9, 13, 14, 18)
+    near = (0, 1, 2, 3, 7, 100, 300)
+    init_hip("D3Q19")
+    ctx = get_context()
+    got = {}
+    for length in (nx, n):
+        grid = grid_factory((length, n, n))
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=cavity_bcs(grid, HalfwayBounceBackBC, EquilibriumBC))
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, steps)
+        ctx.sync()
+        got[length] = {("lo", x, l): a.get_plane(l, x) for x in near for l in pops}
+        got[length].update({("hi", x, l): a.get_plane(l, length - 1 - x) for x in near for l in pops})
+        if length == nx:
+            mid = {(x, l): a.get_plane(l, x) for x in (2000, 2001, 2047, 2048, 3000) for l in pops}
+        for fld in (f_0, f_1, bc_mask, missing_mask):
+            fld.free()
+        del stepper, f_0, f_1, bc_mask, missing_mask, a, b
+        gc.collect()
+    for key in got[n]:
+        assert np.array_equal(got[nx][key], got[n][key]), key
+    for l in pops:
+        for x in (2001, 2047, 2048, 3000):
+            assert np.array_equal(mid[(x, l)], mid[(2000, l)]), (x, l)
+    assert any(np.abs(got[nx][("lo", 3, l)] - got[nx][("lo", 3, l)][0, 0]).max() > 0 for l in pops)  # not a trivial (uniform) comparison
