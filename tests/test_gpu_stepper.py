@@ -377,6 +377,34 @@ def test_two_step_fusion_slab_protocol(shape, walls_cls, steps):
         ctx.set_option("overlap", 1)
 
 
+def test_empty_and_ragged_index_lists():
+    """Edge cases of the index-based BCs: a BC whose index lists are EMPTY tags no cell (the run is the periodic one, bit for bit, the
+    masks are the oracle's); index lists of unequal lengths are refused; indices outside the box are dropped."""
+    vs, pp = init_hip("D3Q19")
+    lat = orc.Lattice("D3Q19")
+    shape = (6, 8, 64)
+    grid = grid_factory(shape)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[FullwayBounceBackBC(indices=[[], [], []]), HalfwayBounceBackBC(indices=[[], [], []])])
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    # (the masker still marks the directions that enter through the faces of the box as missing — on cells that carry no BC, where
+    # nothing reads them: indices_boundary_masker.py:96-99, 131-134)
+    e_bm, e_mm = orc.build_masks(shape, lat, [orc.BC(orc.KIND_FULLWAY_BB, 1, [[], [], []]), orc.BC(orc.KIND_HALFWAY_BB, 2, [[], [], []])])
+    assert not bc_mask.numpy().any() and not e_bm.any() and np.array_equal(missing_mask.numpy(), e_mm.astype(np.uint8))
+    f_np = orc.perturbed_init(shape, lat, seed=59)
+    f_0.assign(f_np)
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.3, 5)
+    z1, zq = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+    assert np.array_equal(f_0.numpy(), orc.run(f_np, z1, zq, [], 1.3, lat, 5))
+    with pytest.raises(Exception):
+        bad = FullwayBounceBackBC(indices=[[1, 2, 3], [1, 2], [1, 2, 3]])
+        IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[bad]).prepare_fields()
+    # an index outside the box is dropped, like an out-of-bounds scatter update in the reference's JAX masker (indices_boundary_masker.py:128)
+    out = FullwayBounceBackBC(indices=[[1, 2], [1, 3], [64, 5]])  # z = 64 is outside; (2, 3, 5) is a cell
+    _, _, bm2, _ = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[out]).prepare_fields()
+    tagged = np.argwhere(bm2.numpy()[0] == out.id)
+    assert tagged.tolist() == [[2, 3, 5]]
+
+
 @pytest.mark.parametrize("walls_cls", [HalfwayBounceBackBC, FullwayBounceBackBC])
 @pytest.mark.parametrize("steps", [4, 5])
 def test_two_step_clean_items_on_the_slack_ring(walls_cls, steps):
