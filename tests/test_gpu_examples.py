@@ -16,6 +16,8 @@ CASES = {
     "turbulent_channel_3d_hip.py": ["--h", "16", "--steps", "300"],
     "windtunnel_3d_hip.py": ["--nx", "96", "--steps", "200", "--every", "100", "--out", "{tmp}"],
     "windtunnel_3d_hip.py --hybrid": ["--nx", "96", "--steps", "200", "--every", "100", "--hybrid"],
+    "mlups_3d_hip.py": ["128", "40", "hip", "fp32/fp32", "--repetitions", "2", "--export_final_velocity"],
+    "mlups_3d_hip.py --velocity_set D3Q27 --collision_model KBC": ["96", "20", "hip", "fp64/fp32"],
 }
 
 
