@@ -33,7 +33,7 @@ class MomentumTransfer(Operator):
             owner = getattr(self.no_slip_bc_instance, "_stepper_ref", None)
             stepper = owner() if owner is not None else None
             if stepper is None:
-                raise RuntimeError("MomentumTransfer(HybridBC): the BC is not part of a live stepper (prepare_fields / a step come first)")
+                raise RuntimeError("MomentumTransfer(HybridBC): the BC is not part of a live stepper (stepper.prepare_fields() comes first)")
             force = stepper._native_stepper().momentum_transfer(self.no_slip_bc_instance.id, f_0, bc_mask, missing_mask)
             return force[3 - self.velocity_set.d :].astype(self.compute_dtype)
         desc = self.no_slip_bc_instance._hip_descriptor()

@@ -94,10 +94,6 @@ class IncompressibleNavierStokesStepper(Stepper):
                                         self._store_code, descs)
             if isinstance(self.collision, SmagorinskyLESBGK):
                 self._native.set_smagorinsky(self.collision.smagorinsky_coef)
-            import weakref
-
-            for bc in self.boundary_conditions:
-                bc._stepper_ref = weakref.ref(self)  # (MomentumTransfer of a HybridBC reads this stepper's tables)
             for bc in self.boundary_conditions:
                 table = bc._profile_table(self.grid) if hasattr(bc, "_profile_table") else None
                 if table is not None:
@@ -126,6 +122,10 @@ class IncompressibleNavierStokesStepper(Stepper):
         return f_0, f_1, bc_mask, missing_mask
 
     def _process_boundary_conditions(self, boundary_conditions, f_1, bc_mask, missing_mask):
+        import weakref
+
+        for bc in boundary_conditions:
+            bc._stepper_ref = weakref.ref(self)  # (MomentumTransfer of a HybridBC / profile wall reads this stepper's tables)
         check_bc_overlaps(boundary_conditions, self.velocity_set.d, self.compute_backend)
         masker = IndicesBoundaryMasker(self.velocity_set, self.precision_policy, self.compute_backend, grid=self.grid)
         with_indices = [bc for bc in boundary_conditions if getattr(bc, "indices", None) is not None]
