@@ -255,9 +255,19 @@ def voxelize_stl(stl_filename, length_lbm_unit=None, transformation_matrix=None,
 # ---- units ---------------------------------------------------------------------------------------------------------------------
 
 class UnitConvertor:
-    """Lattice <-> physical units from one velocity pair and the voxel size (utils.py:450-537): dt = dx u_lbm / u_phys; lengths scale
-    with dx, times with dt, velocities with dx / dt, viscosities with dx^2 / dt, densities with the reference density; a lattice
-    pressure is rho c_s^2 = 1/3 at the reference pressure."""
+    """Lattice <-> physical units from one velocity pair and the voxel size (utils.py:450-537): dt = dx u_lbm / u_phys.  Every quantity
+    has ONE scale — its value of one lattice unit in physical units — and the pair of methods ``<quantity>_to_lbm`` /
+    ``<quantity>_to_physical`` divides / multiplies by it: length dx, time dt, velocity dx / dt, viscosity dx^2 / dt, density the
+    reference density.  Pressure is the exception: ``pressure_to_lbm`` returns the perturbation p' / (rho_ref u_ref^2) about the reference
+    pressure, ``pressure_to_physical`` takes a lattice pressure rho c_s^2 (1/3 at the reference state)."""
+
+    _SCALES = {
+        "length": lambda c: c.reference_length,
+        "time": lambda c: c.reference_time,
+        "density": lambda c: c.reference_density,
+        "velocity": lambda c: c.reference_velocity,
+        "viscosity": lambda c: c.reference_length**2 / c.reference_time,
+    }
 
     def __init__(self, velocity_lbm_unit, velocity_physical_unit, voxel_size_physical_unit, density_physical_unit=1.2041,
                  pressure_physical_unit=1.101325e5):
@@ -266,47 +276,21 @@ class UnitConvertor:
         self.velocity_phys_unit = velocity_physical_unit
         self.reference_density = density_physical_unit
         self.reference_pressure = pressure_physical_unit
-
-    @property
-    def time_step_physical(self):
-        return self.voxel_size * self.velocity_lbm_unit / self.velocity_phys_unit
-
-    reference_length = property(lambda self: self.voxel_size)
-    reference_time = property(lambda self: self.time_step_physical)
-    reference_velocity = property(lambda self: self.reference_length / self.reference_time)
-
-    def length_to_lbm(self, length_phys):
-        return length_phys / self.reference_length
-
-    def length_to_physical(self, length_lbm):
-        return length_lbm * self.reference_length
-
-    def time_to_lbm(self, time_phys):
-        return time_phys / self.reference_time
-
-    def time_to_physical(self, time_lbm):
-        return time_lbm * self.reference_time
-
-    def density_to_lbm(self, rho_phys):
-        return rho_phys / self.reference_density
-
-    def density_to_physical(self, rho_lbm):
-        return rho_lbm * self.reference_density
-
-    def velocity_to_lbm(self, velocity_phys):
-        return velocity_phys / self.reference_velocity
-
-    def velocity_to_physical(self, velocity_lbm):
-        return velocity_lbm * self.reference_velocity
-
-    def viscosity_to_lbm(self, viscosity_phys):
-        return viscosity_phys * self.reference_time / self.reference_length**2
-
-    def viscosity_to_physical(self, viscosity_lbm):
-        return viscosity_lbm * self.reference_length**2 / self.reference_time
+        self.reference_length = voxel_size_physical_unit
+        self.time_step_physical = self.reference_time = voxel_size_physical_unit * velocity_lbm_unit / velocity_physical_unit
+        self.reference_velocity = self.reference_length / self.reference_time
 
     def pressure_to_lbm(self, pressure_phys):
-        return (pressure_phys - self.reference_pressure) / self.reference_density / self.reference_velocity**2
+        return (pressure_phys - self.reference_pressure) / (self.reference_density * self.reference_velocity**2)
 
     def pressure_to_physical(self, pressure_lbm):
         return self.reference_pressure + (pressure_lbm - 1.0 / 3.0) * self.reference_density * self.reference_velocity**2
+
+
+def _add_conversions(cls):
+    for quantity, scale in cls._SCALES.items():
+        setattr(cls, f"{quantity}_to_lbm", lambda self, value, _s=scale: value / _s(self))
+        setattr(cls, f"{quantity}_to_physical", lambda self, value, _s=scale: value * _s(self))
+
+
+_add_conversions(UnitConvertor)
