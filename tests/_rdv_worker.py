@@ -29,11 +29,25 @@ def main():
     if n > 2:
         ok &= (got[(r + 1) % n] == np.array([(r + 1) % n, -1])).all()
     ok &= rdv.route({}) == {}
+    # bulk frames (several MB: the shared-memory mailbox has to grow; a frame to oneself; uneven sizes), twice in a row
+    want_shm = os.environ.get("XLB_RDV_SHM", "1") != "0"
+    ok &= rdv._shm == want_shm
+    for rep in range(2):
+        big = {(r + 1) % n: bytes([r + rep]) * (3_000_000 + 1000 * r), r: b"self" + bytes([rep])}
+        got = rdv.route(big)
+        src = (r - 1) % n
+        ok &= got[r] == b"self" + bytes([rep]) and len(got[src]) == 3_000_000 + 1000 * src and got[src][:2] == bytes([src + rep]) * 2 and got[src][-1] == src + rep
+        ok &= set(got) == {r, src}
+    if want_shm:
+        ok &= os.path.exists(rdv._box_path(r))
     rdv.barrier()
     flags = rdv.all_gather(bool(ok))
     if r == 0:
         print("RDV_OK" if all(flags) else f"RDV_FAIL {flags}", flush=True)
+    path = rdv._box_path(r)
     rdv.close()
+    if os.path.exists(path):  # the mailbox file goes with the rendezvous
+        sys.exit(2)
     sys.exit(0 if all(flags) else 1)
 
 

@@ -28,6 +28,13 @@ def test_collectives_plain_processes(world):
     assert "RDV_OK" in outs[0][0]
 
 
+def test_route_through_the_hub_when_shared_memory_is_off():
+    """XLB_RDV_SHM=0 (or ranks on different hosts): bulk frames travel through the TCP hub instead of the /dev/shm mailboxes — same results."""
+    codes, outs = spawn(3, free_port(), {"XLB_RDV_SHM": "0"})
+    assert codes == [0] * 3, outs
+    assert "RDV_OK" in outs[0][0]
+
+
 def test_hub_skips_a_port_that_is_taken():
     """MASTER_PORT itself occupied by somebody else (as under torch.distributed.run, whose store owns it): the hub moves to
     the next candidate and the other ranks find it there."""

@@ -18,9 +18,11 @@ the launcher's own store, so the search starts one above it.  Every connection s
 job token (hash of the job description), so a foreign listener on a candidate port is skipped.
 """
 
+import atexit
 import hashlib
 import io
 import json
+import mmap
 import os
 import socket
 import struct
@@ -114,6 +116,73 @@ def _unpack_many(data):
     return out
 
 
+class _Mailbox:
+    """A file in /dev/shm mapped into memory: [u64 payload bytes][u32 n]{i32 dst, u64 offset, u64 length} x n, frames.  The owner rewrites
+    it per route() call (growing the file when needed); readers map it lazily and re-map when it has grown."""
+
+    _HEAD = 12
+
+    def __init__(self, path, create):
+        self.path, self.owner = path, create
+        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        self.fd = os.open(path, flags, 0o600)
+        self.size = 0
+        self.map = None
+        if create:
+            self._resize(1 << 20)
+
+    def _resize(self, size):
+        if self.map is not None:
+            self.map.close()
+        os.ftruncate(self.fd, size)
+        self.map = mmap.mmap(self.fd, size)
+        self.size = size
+
+    def _remap(self, need):
+        if self.map is None or need > self.size:
+            if self.map is not None:
+                self.map.close()
+            self.size = os.fstat(self.fd).st_size
+            self.map = mmap.mmap(self.fd, self.size)
+
+    def write(self, frames):
+        """Lay the frames out; returns the number of bytes a reader has to see (0: nothing to read)."""
+        if not frames:
+            return 0
+        table = self._HEAD + 20 * len(frames)
+        total = table + sum(len(v) for v in frames.values())
+        if total > self.size:
+            self._resize(max(total, 2 * self.size))
+        m, off = self.map, table
+        struct.pack_into("<QI", m, 0, total, len(frames))
+        for i, (dst, data) in enumerate(frames.items()):
+            struct.pack_into("<iQQ", m, self._HEAD + 20 * i, int(dst), off, len(data))
+            m[off : off + len(data)] = data
+            off += len(data)
+        return total
+
+    def read(self, me, need):
+        self._remap(need)
+        m = self.map
+        total, n = struct.unpack_from("<QI", m, 0)
+        for i in range(n):
+            dst, off, ln = struct.unpack_from("<iQQ", m, self._HEAD + 20 * i)
+            if dst == me:
+                return bytes(m[off : off + ln])
+        return None
+
+    def close(self, unlink):
+        try:
+            if self.map is not None:
+                self.map.close()
+            os.close(self.fd)
+            if unlink:
+                os.unlink(self.path)
+        except OSError:
+            pass
+        self.map = None
+
+
 class Rendezvous:
     def __init__(self, rank, world, addr="127.0.0.1", port=29500, timeout=None):
         self.rank, self.world = int(rank), int(world)
@@ -123,11 +192,15 @@ class Rendezvous:
         self._peers = {}   # hub: rank -> socket
         self._hub = None   # others: socket to rank 0
         self._listener = None
+        self._box = None   # this rank's shared-memory mailbox (route through /dev/shm when every rank sits on this host)
+        self._box_views = {}
+        self._shm = False
         if self.world > 1:
             if self.rank == 0:
                 self._serve()
             else:
                 self._connect()
+            self._shm = self._agree_on_shm()
 
     # -- set-up
     def _serve(self):
@@ -210,11 +283,58 @@ class Rendezvous:
             parts = _unpack_many(_recv(self._hub))
         return [parts[r] for r in range(self.world)]
 
+    # -- bulk point-to-point through shared memory (one node): the hub only carries the two barriers
+    def _box_path(self, r):
+        return f"/dev/shm/xlbamd-{self._token.hex()}-{r}"
+
+    def _agree_on_shm(self):
+        """True when every rank runs on this host and could create its mailbox file (XLB_RDV_SHM=0 forces the hub path)."""
+        ok, ident = False, ""
+        try:
+            if os.environ.get("XLB_RDV_SHM", "1") != "0" and os.path.isdir("/dev/shm"):
+                ident = socket.gethostname() + ":" + open("/proc/sys/kernel/random/boot_id").read().strip()
+                self._box = _Mailbox(self._box_path(self.rank), create=True)
+                atexit.register(self._drop_box)  # (a job that never calls close() must not leave its file in /dev/shm: it is memory)
+                ok = True
+        except OSError:
+            ok = False
+        views = self.all_gather([bool(ok), ident])
+        agreed = all(v[0] for v in views) and len({v[1] for v in views}) == 1
+        if not agreed and self._box is not None:
+            self._box.close(unlink=True)
+            self._box = None
+        return agreed
+
+    def _drop_box(self):
+        if self._box is not None:
+            self._box.close(unlink=True)
+            self._box = None
+
+    def _route_shm(self, outgoing):
+        mine = outgoing.pop(self.rank, None)
+        size = self._box.write(outgoing)
+        sizes = [struct.unpack("<Q", b)[0] for b in self.all_gather_bytes(struct.pack("<Q", size))]  # barrier 1: every mailbox is written
+        got = {} if mine is None else {self.rank: mine}
+        for r in range(self.world):
+            if r == self.rank or sizes[r] == 0:
+                continue
+            view = self._box_views.get(r)
+            if view is None:
+                view = self._box_views[r] = _Mailbox(self._box_path(r), create=False)
+            frame = view.read(self.rank, sizes[r])
+            if frame is not None:
+                got[r] = frame
+        self.all_gather_bytes(b"")  # barrier 2: everybody has read; the mailboxes may be rewritten
+        return got
+
     def route(self, outgoing):
-        """Point-to-point through the hub: ``outgoing`` = {destination rank: bytes}; returns {source rank: bytes}.
-        Collective: every rank calls it (with an empty dict when it has nothing to send)."""
+        """Point-to-point: ``outgoing`` = {destination rank: bytes}; returns {source rank: bytes}.  Collective: every rank calls it
+        (with an empty dict when it has nothing to send).  On one node the payload goes through shared-memory mailboxes and the hub
+        only synchronises; otherwise everything goes through the hub."""
         if self.world == 1:
             return {0: outgoing[0]} if 0 in outgoing else {}
+        if self._shm:
+            return self._route_shm(dict(outgoing))
         if self.rank == 0:
             boxes = {r: {} for r in range(self.world)}
             for dst, data in outgoing.items():
@@ -250,6 +370,13 @@ class Rendezvous:
                 except OSError:
                     pass
         self._peers, self._hub, self._listener = {}, None, None
+        for view in self._box_views.values():
+            view.close(unlink=False)
+        self._box_views = {}
+        if self._box is not None:
+            self._box.close(unlink=True)
+            self._box = None
+        self._shm = False
 
 
 def from_env(timeout=None):
