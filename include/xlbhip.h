@@ -139,6 +139,13 @@ int xlbhip_field_download(const xlbhip_field* f, void* host, size_t host_bytes);
  * host-staged halo transports and tests */
 int xlbhip_field_plane_download(const xlbhip_field* f, int population, int storage_plane, void* host, size_t bytes);
 int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane, const void* host, size_t bytes);
+/* Tell the library that somebody wrote the field behind its back — through a zero-copy alias (Field.__dlpack__ /
+ * __cuda_array_interface__, the replacement of utils.py:340-447's ToJAX): bumps the contents version that the stepper's
+ * per-mask caches (meta words, clean-item flags, end-plane scan) are keyed on */
+int xlbhip_field_touch(xlbhip_field* f);
+/* free / total device memory (hipMemGetInfo): the Python stepper refuses to pair reference-style calls when the
+ * temporary third field a read of the virtual f(t+1) needs would not fit */
+int xlbhip_mem_info(xlbhip_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int xlbhip_field_info(const xlbhip_field* f, int* cardinality, int* nx, int* ny, int* nz, int* dtype, int* halo,
                       uint64_t* plane_stride_elems, void** device_ptr);
 

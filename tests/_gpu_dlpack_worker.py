@@ -45,7 +45,42 @@ def main():
     m = g2.create_field(1, dtype=Precision.UINT8, fill_value=3)
     tm = torch.from_dlpack(m)
     assert tuple(tm.shape) == (1, 8, 16) and tm.dtype == torch.uint8 and int(tm.sum().item()) == 3 * 128
+    edited_mask_is_seen()
     print("DLPACK_OK")  # (t, t2, tm die at interpreter shutdown: the deleter thunk is built to survive that)
+
+
+def edited_mask_is_seen():
+    """the stepper caches the two-step kernel's meta words / clean flags on the masks' contents
+    version; a mask edited through its zero-copy alias goes through no C-ABI writer.  An exported mask therefore counts
+    as modified on every use (xlbhip_field_touch): the second run must see the edit."""
+    from oracle import xlb_numpy as orc
+    from xlb_amd.default_config import get_context
+    from xlb_amd.operator.boundary_condition import FullwayBounceBackBC
+    from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
+
+    from _util import hip_cavity_3d
+
+    shape = (12, 16, 64)
+    grid, bcs, lat, obcs = hip_cavity_3d(shape, FullwayBounceBackBC)
+    get_context().set_option("fuse2", 2)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bm, mm = stepper.prepare_fields()
+    f_np = orc.perturbed_init(shape, lat, seed=3)
+    f_0.assign(f_np)
+    o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    t_bm = torch.as_tensor(bm, device="cuda")  # writable alias of bc_mask
+    f_0, f_1 = stepper.run(f_0, f_1, bm, mm, 1.3, 4)  # pairs: meta words cached for these masks
+    e = orc.run(f_np, o_bm, o_mm, obcs, 1.3, lat, 4)
+    assert np.array_equal(f_0.numpy(), e)
+    # open a window in the y = 0 wall: those cells become plain fluid (periodic wrap), in the oracle's mask too
+    t_bm[0, 3:9, 0, 20:40] = 0
+    torch.cuda.synchronize()
+    o_bm2 = o_bm.copy()
+    o_bm2[0, 3:9, 0, 20:40] = 0
+    assert np.array_equal(bm.numpy(), o_bm2)
+    f_0, f_1 = stepper.run(f_0, f_1, bm, mm, 1.3, 4)
+    assert np.array_equal(f_0.numpy(), orc.run(e, o_bm2, o_mm, obcs, 1.3, lat, 4)), "edit of an exported bc_mask was not seen"
+    get_context().set_option("fuse2", 1)
 
 
 if __name__ == "__main__":

@@ -123,3 +123,55 @@ def test_editing_the_masks_flushes_the_deferred_step():
     saved = bm.numpy()  # any access to the mask counts
     assert stepper._deferred is None and np.array_equal(saved, o_bm)
     assert np.array_equal(f_1.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 1))
+
+
+def test_failed_materialisation_keeps_the_step_owed(monkeypatch):
+    """reading the virtual f(t+1) allocates a temporary third field.  If that allocation fails the hook
+    must stay: the next reader raises again (or succeeds once memory is back) — it is never handed f(t) for f(t+1)."""
+    stepper, (a, b, bm, mm), lat, obcs, f_np, o_bm, o_mm = setup()
+    stepper(a, b, bm, mm, 1.2, 0)
+    stepper(b, a, bm, mm, 1.2, 1)  # fused: b holds f(t+1) virtually
+    assert stepper._n_fused_pairs == 1
+    real = stepper.grid.create_field
+
+    def no_memory(*args, **kw):
+        raise MemoryError("hipMalloc failed (simulated)")
+
+    monkeypatch.setattr(stepper.grid, "create_field", no_memory)
+    with pytest.raises(MemoryError):
+        b.numpy()
+    with pytest.raises(MemoryError):  # still owed: not f(t)
+        b.numpy()
+    assert stepper._n_materialised == 0
+    monkeypatch.setattr(stepper.grid, "create_field", real)
+    assert np.array_equal(b.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 1))
+    assert np.array_equal(a.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 2))
+
+
+def test_run_after_a_pair_does_not_materialise_what_it_overwrites():
+    """stepper.run(f_0, f_1, ...) overwrites f_1 with its first step; a virtual f(t+1) there is dropped, not
+    materialised through a third field."""
+    stepper, (a, b, bm, mm), lat, obcs, f_np, o_bm, o_mm = setup()
+    stepper(a, b, bm, mm, 1.2, 0)
+    stepper(b, a, bm, mm, 1.2, 1)  # a: f(t+2); b: virtual f(t+1)
+    cur, oth = stepper.run(a, b, bm, mm, 1.2, 3)
+    assert stepper._n_materialised == 0
+    assert np.array_equal(cur.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 5))
+    # zero steps overwrite nothing: the virtual field stays readable
+    stepper2, (c, d, bm2, mm2), *_ = setup()
+    stepper2(c, d, bm2, mm2, 1.2, 0)
+    stepper2(d, c, bm2, mm2, 1.2, 1)
+    stepper2.run(c, d, bm2, mm2, 1.2, 0)
+    assert np.array_equal(d.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.2, lat, 1)) and stepper2._n_materialised == 1
+
+
+def test_no_pairing_without_room_for_a_third_field(monkeypatch):
+    """where the two population fields just fit, reference-style calls are not paired (single steps need no
+    temporary), instead of failing later inside an innocent read."""
+    stepper, (f_0, f_1, bm, mm), lat, obcs, f_np, o_bm, o_mm = setup()
+    monkeypatch.setattr(type(stepper._ctx), "mem_info", lambda self: (1 << 20, 1 << 38))
+    for i in range(4):
+        f_0, f_1 = stepper(f_0, f_1, bm, mm, 1.4, i)
+        f_0, f_1 = f_1, f_0
+    assert stepper._n_fused_pairs == 0 and stepper._deferred is None
+    assert np.array_equal(f_0.numpy(), orc.run(f_np, o_bm, o_mm, obcs, 1.4, lat, 4))

@@ -61,6 +61,8 @@ SIGNATURES = {
     "xlbhip_field_download": [_p, _p, C.c_size_t],
     "xlbhip_field_plane_download": [_p, _i, _i, _p, C.c_size_t],
     "xlbhip_field_plane_upload": [_p, _i, _i, _p, C.c_size_t],
+    "xlbhip_field_touch": [_p],
+    "xlbhip_mem_info": [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "xlbhip_field_info": [_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                           C.POINTER(C.c_uint64), _pp],
     "xlbhip_stream": [_p, _i, _p, _p],
@@ -185,6 +187,12 @@ class Context:
         check(load().xlbhip_get_option(self.handle, key.encode(), C.byref(v)))
         return v.value
 
+    def mem_info(self):
+        """(free, total) device memory in bytes."""
+        fr, tot = C.c_uint64(), C.c_uint64()
+        check(load().xlbhip_mem_info(self.handle, C.byref(fr), C.byref(tot)))
+        return fr.value, tot.value
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cus, hbm = _i(), C.c_uint64()
@@ -304,10 +312,21 @@ class Field:
     def handle(self):
         if self._hook is not None:
             hook, self._hook = self._hook, None
-            hook(self)
+            try:
+                hook(self)
+            except BaseException:
+                # the deferred work did not happen: whoever looks next must not see the field as if it had (a failed
+                # materialisation of a virtual f(t+1) would otherwise hand out f(t))
+                if self._hook is None:
+                    self._hook = hook
+                raise
         if not self._h:
             raise HipBackendError("field already destroyed")
         return self._h
+
+    def touch(self):
+        """The contents changed behind the library's back (a write through a zero-copy alias): invalidate what is cached on them."""
+        check(load().xlbhip_field_touch(self.handle))
 
     @property
     def nbytes_host(self):
@@ -444,7 +463,13 @@ def make_bc_desc(bc_id, kind, values):
 
 
 def _h(field):
-    return field.handle if field is not None else None
+    """handle of an optional mask argument.  A mask that was exported as a writable zero-copy alias (DLPack / CUDA array
+    interface) may have been edited by the consumer without any C-ABI call: it counts as modified every time it is used."""
+    if field is None:
+        return None
+    if field._pinned:
+        field.touch()
+    return field.handle
 
 
 class Stepper:

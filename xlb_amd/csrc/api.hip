@@ -260,6 +260,7 @@ int xlbhip_field_create(xlbhip_ctx* c, int card, int nx, int ny, int nz, int dty
     XLB_FAIL("hipMalloc(%zu bytes) failed: %s", f->alloc_bytes, hipGetErrorString(e));
   }
   f->data = static_cast<char*>(f->base) + GUARD_BYTES;
+  touch(f);  // a fresh contents version: no cache entry of a freed field at this address can match
   *out = f;
   if (dtype == XLBHIP_MISSING) {
     XLB_REQUIRE(fill == 0.0, "missing_mask fill must be 0");
@@ -323,6 +324,22 @@ int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int byt
     hipLaunchKernelGGL(k_copy<u32x4>, blocks_capped(n), 256, 0, st, (const u32x4*)src->data, (u32x4*)dst->data, n);
   }
   XLB_HIP(hipGetLastError());
+  return 0;
+}
+
+int xlbhip_field_touch(xlbhip_field* f) {
+  XLB_REQUIRE(f, "field is null");
+  touch(f);
+  return 0;
+}
+
+int xlbhip_mem_info(xlbhip_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
+  XLB_REQUIRE(c, "ctx is null");
+  XLB_HIP(hipSetDevice(c->device));
+  size_t fr = 0, tot = 0;
+  XLB_HIP(hipMemGetInfo(&fr, &tot));
+  if (free_bytes) *free_bytes = fr;
+  if (total_bytes) *total_bytes = tot;
   return 0;
 }
 
@@ -992,7 +1009,7 @@ struct xlbhip_stepper {
   size_t meta_cells = 0;
   // two-step kernel: per launch geometry (x_begin, x_count, segments, tile order?, swizzle) the per-block "no boundary
   // cell" flags; dropped whenever the meta words are rebuilt
-  std::map<std::array<int, 5>, uint8_t*> clean_cache;
+  std::map<std::array<int, 8>, uint8_t*> clean_cache;
   // the masks (address + contents version) the meta words were built from: xlbhip_step2 called per pair (the Python
   // stepper pairing reference-style calls) must not rebuild them every time
   const xlbhip_field* meta_bc = nullptr;
@@ -1193,7 +1210,9 @@ static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
   if (s->lattice == XLBHIP_D3Q27) return s->collision == XLBHIP_KBC ? launch_step2_d3q27_kbc(p) : launch_step2_d3q27_bgk(p);
   p.clean = nullptr;
   if (p.has_bc && p.meta && opt(s->ctx, "fuse2_clean", 1)) {
-    const std::array<int, 5> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, (p.tile_order ? 1 : 0) + 2 * p.tile_oy + 1024 * p.tile_oz, p.xcd_swizzle};
+    // everything the block -> (tile, x-segment) mapping depends on: the flags say "no boundary cell in THIS block's item"
+    const std::array<int, 8> key = {p.x_begin, p.x_count, p.x_segments * 64 + p.x_cap, (p.tile_order ? 1 : 0) + 2 * p.tile_oy + 1024 * p.tile_oz,
+                                    p.xcd_swizzle, p.tile_order ? s->order_mode : -1, p.tile_ty, p.tile_tz};
     auto it = s->clean_cache.find(key);
     if (it == s->clean_cache.end()) {
       uint8_t* flags = nullptr;
@@ -1414,6 +1433,7 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     };
     deal(hull, opt(c, "fuse2_lpt", 1) != 3);
     deal(inner, true);
+    drop_clean_cache(s);  // the flags were computed for the old block -> tile mapping
     if (s->tile_order) XLB_HIP(hipFree(s->tile_order));
     s->tile_order = nullptr;
     XLB_HIP(hipMalloc(&s->tile_order, order.size() * sizeof(uint32_t)));

@@ -34,9 +34,12 @@ _MAGIC = b"XLBRDV1\0"
 _N_CANDIDATES = 24
 
 
-def _job_token(addr, port, world):
+def _job_token(addr, port, world, listen_port=None):
+    """Hash of the job description; with ``listen_port`` also of the port the hub really bound (a hello meant for the
+    hub of one candidate port is refused by a hub that listens on another one)."""
     job = os.environ.get("XLB_JOB_ID") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
-    return hashlib.sha256(f"{addr}|{port}|{world}|{job}".encode()).digest()[:16]
+    tail = "" if listen_port is None else f"|{listen_port}"
+    return hashlib.sha256(f"{addr}|{port}|{world}|{job}{tail}".encode()).digest()[:16]
 
 
 def candidate_ports(master_port):
@@ -124,7 +127,8 @@ class _Mailbox:
 
     def __init__(self, path, create):
         self.path, self.owner = path, create
-        flags = os.O_RDWR | (os.O_CREAT | os.O_TRUNC if create else 0)
+        # the owner's file must not exist yet (the name carries a per-job nonce) and must not be a link somebody planted
+        flags = os.O_RDWR | os.O_NOFOLLOW | (os.O_CREAT | os.O_EXCL if create else 0)
         self.fd = os.open(path, flags, 0o600)
         self.size = 0
         self.map = None
@@ -189,6 +193,7 @@ class Rendezvous:
         self.addr, self.port = addr, int(port)
         self.timeout = float(timeout if timeout is not None else os.environ.get("XLB_RDV_TIMEOUT", 600))
         self._token = _job_token(addr, self.port, self.world)
+        self._nonce = ""   # drawn by rank 0 once the star stands: names of this job's /dev/shm files
         self._peers = {}   # hub: rank -> socket
         self._hub = None   # others: socket to rank 0
         self._listener = None
@@ -232,7 +237,8 @@ class Rendezvous:
                 conn.settimeout(10.0)
                 hello = _recv_exact(conn, len(_MAGIC) + 16 + 4)
                 r = struct.unpack("<i", hello[-4:])[0]
-                if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC) : -4] != self._token or not (0 < r < self.world) or r in self._peers:
+                want = _job_token(self.addr, self.port, self.world, self.listen_port)
+                if hello[: len(_MAGIC)] != _MAGIC or hello[len(_MAGIC) : -4] != want or not (0 < r < self.world) or r in self._peers:
                     conn.close()
                     continue
                 conn.sendall(b"OK")
@@ -244,10 +250,10 @@ class Rendezvous:
 
     def _connect(self):
         deadline = time.monotonic() + self.timeout
-        hello = _MAGIC + self._token + struct.pack("<i", self.rank)
         ports = candidate_ports(self.port)
         while True:
             for p in ports:
+                hello = _MAGIC + _job_token(self.addr, self.port, self.world, p) + struct.pack("<i", self.rank)
                 s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 s.settimeout(3.0)
                 try:
@@ -285,11 +291,13 @@ class Rendezvous:
 
     # -- bulk point-to-point through shared memory (one node): the hub only carries the two barriers
     def _box_path(self, r):
-        return f"/dev/shm/xlbamd-{self._token.hex()}-{r}"
+        return f"/dev/shm/xlbamd-{self._token.hex()[:12]}-{self._nonce}-{r}"
 
     def _agree_on_shm(self):
         """True when every rank runs on this host and could create its mailbox file (XLB_RDV_SHM=0 forces the hub path)."""
         ok, ident = False, ""
+        # a fresh nonce per job: two jobs started from the same environment must not share (truncate) each other's mailboxes
+        self._nonce = self.broadcast(os.urandom(8).hex() if self.rank == 0 else None, src=0)
         try:
             if os.environ.get("XLB_RDV_SHM", "1") != "0" and os.path.isdir("/dev/shm"):
                 ident = socket.gethostname() + ":" + open("/proc/sys/kernel/random/boot_id").read().strip()

@@ -164,7 +164,22 @@ class IncompressibleNavierStokesStepper(Stepper):
         if not self.backend_config.get("lazy_pairs", True) or f_0.halo != 0 or f_0._pinned or f_1._pinned:
             return False
         # (asked every time: the answer follows the backend options — fuse2, ... — and the masks' contents; host logic only)
-        return self._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        if not self._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask):
+            return False
+        return self._room_for_a_third_field(f_0)
+
+    def _room_for_a_third_field(self, f):
+        """After a fused pair one field holds f(t+1) only virtually, and reading it takes a temporary third population field
+        (_materialise).  A run whose two fields just fit — the reference's protocol needs no more — must not fail with
+        hipErrorOutOfMemory in an innocent read: without room for that field (plus 1/16 slack) the calls are not paired.
+        hipMemGetInfo is asked at the first pairing and every 256th afterwards."""
+        self._room_calls = getattr(self, "_room_calls", 0) + 1
+        if getattr(self, "_room_ok", None) is None or self._room_calls % 256 == 0:
+            info = f.info()
+            need = info["plane_stride"] * info["cardinality"] * f.dtype.itemsize
+            free, _ = self._ctx.mem_info()
+            self._room_ok = free >= need + need // 16
+        return self._room_ok
 
     def _flush_deferred(self, *_):
         """Enqueue the deferred step as a single step (some other use of its fields came first)."""
@@ -173,7 +188,15 @@ class IncompressibleNavierStokesStepper(Stepper):
             return
         f_src, f_dst, bcm, miss, omega, t = d
         self._unhook(f_src, f_dst, bcm, miss)
-        self._native_stepper().step(f_src, f_dst, bcm, miss, omega, t)
+        try:
+            self._native_stepper().step(f_src, f_dst, bcm, miss, omega, t)
+        except BaseException:
+            # not enqueued: the step stays owed (the next use of any of its fields tries again and raises again)
+            self._deferred = d
+            for fld in (f_src, f_dst, bcm, miss):
+                if fld is not None:
+                    fld._hook = self._flush_deferred
+            raise
 
     @staticmethod
     def _unhook(*fields):
@@ -184,10 +207,15 @@ class IncompressibleNavierStokesStepper(Stepper):
     def _materialise(self, field, bcm, miss, omega, t):
         """`field` should hold f(t+1) but its buffer holds f(t) (a fused pair passed it by): one single step through a
         temporary field, whose buffer the field then adopts."""
-        field._hook = None
-        self._n_materialised += 1
+        # the temporary comes first: if it cannot be allocated this raises with the hook still owed (Field.handle puts it
+        # back), so the next reader raises again instead of being handed f(t) for f(t+1)
         tmp = self.grid.create_field(cardinality=self.velocity_set.q, dtype=self.precision_policy.store_precision)
-        self._native_stepper().step(field, tmp, bcm, miss, omega, t)
+        try:
+            self._native_stepper().step(field, tmp, bcm, miss, omega, t)  # (field._hook is None while its hook runs)
+        except BaseException:
+            tmp.free()
+            raise
+        self._n_materialised += 1
         field._h, tmp._h = tmp._h, field._h
         tmp.free()
 
@@ -228,9 +256,17 @@ class IncompressibleNavierStokesStepper(Stepper):
             self._ctx._flushers.append(weakref.ref(self))
         return True
 
+    @staticmethod
+    def _drop_virtual_destination(f_1, n_steps):
+        """The first of n >= 1 steps overwrites f_1 entirely: a virtual f(t+1) in it (left by a fused pair of reference-style
+        calls) needs no materialisation — which would allocate a third field and run an extra step for nothing."""
+        if n_steps >= 1 and isinstance(f_1._hook, _Materialise):
+            f_1._hook = None
+
     def run(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """``n_steps`` x (step, swap) in native code; returns (f_current, f_other)."""
         self._flush_deferred()
+        self._drop_virtual_destination(f_1, n_steps)
         if f_0.halo > 0 and self._ctx.get_option("external_halo"):
             return self._run_host_staged(f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep)
         in_b = self._native_stepper().run(f_0, f_1, bc_mask, missing_mask, omega, first_timestep, n_steps)
@@ -239,6 +275,7 @@ class IncompressibleNavierStokesStepper(Stepper):
     def run_timed(self, f_0, f_1, bc_mask, missing_mask, omega, n_steps, first_timestep=0):
         """As :meth:`run`; also returns the device time in ms measured with HIP events."""
         self._flush_deferred()
+        self._drop_virtual_destination(f_1, n_steps)
         if f_0.halo > 0 and self._ctx.get_option("external_halo"):
             import time
 
