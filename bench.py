@@ -68,14 +68,34 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process would see, counted without touching HIP (the launcher must not initialise it): KFD topology
+    nodes with compute units, capped by a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list."""
+    n = 0
+    try:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(top):
+            for line in open(os.path.join(top, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var, "").strip()
+        if v:
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
+
+
 def launch(args, argv):
     """Parent of a self-launched N-rank run.  Touches neither HIP nor xlb_amd: the children are fresh processes."""
     n = args.gpus
     port = free_port()
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XLB_JOB_ID=f"bench-{os.getpid()}-{port}",
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    if os.environ.get("XLB_BENCH_TRANSPORT", "rccl") == "host":
-        base.setdefault("XLB_HIP_DEVICE", "0")  # rehearsal: every rank on ONE GPU
+    if os.environ.get("XLB_BENCH_TRANSPORT", "auto") == "host" or (os.environ.get("XLB_BENCH_TRANSPORT", "auto") in ("ipc", "ipc_or_host")
+                                                                   and visible_gpus() < n):
+        base.setdefault("XLB_HIP_DEVICE", "0")  # rehearsal: every rank on ONE GPU (RCCL refuses that; ipc and host do not)
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
@@ -310,11 +330,12 @@ def main():
     from xlb_amd.operator.boundary_condition import EquilibriumBC, FullwayBounceBackBC, HalfwayBounceBackBC
     from xlb_amd.operator.stepper import IncompressibleNavierStokesStepper
 
-    # XLB_BENCH_TRANSPORT=host: rehearsal of the N > 1 code path with all ranks on ONE GPU (ghost planes through the
-    # host; RCCL refuses two ranks on a device).  Numbers from it are not benchmark results.
-    # Default: RCCL, and if its communicator cannot be built (an error, not a hang) every rank falls back to the host transport
-    # and the JSON says so — a slow number with its reason instead of no number.
-    transport = os.environ.get("XLB_BENCH_TRANSPORT", "rccl_or_host")
+    # Halo transport (xlb_amd.distribute.init_process_group).  Default "auto": RCCL send / recv (the north-star's transport); if its
+    # communicator cannot be built or fails the start-up self-check (an error, not a hang) every rank moves on to "ipc" — the
+    # neighbours' fields mapped through HIP IPC and pulled by copy-engine copies on the communication stream — and only then to
+    # the host-staged debugging transport; the JSON names what ran and why.  XLB_BENCH_TRANSPORT=ipc / host / rccl force one;
+    # ipc and host also work with every rank on ONE GPU (rehearsals on a one-GPU box: not benchmark results).
+    transport = os.environ.get("XLB_BENCH_TRANSPORT", "auto")
     # halfway walls on both x faces: no population is ever pulled across them (every such pull is a missing direction
     # that the wall redirects), so the ring is a chain.  Fullway wall cells DO exchange (inert) populations with their
     # periodic images in the reference (roll-based streaming), so that workload keeps the ring.
@@ -376,6 +397,10 @@ def main():
     elapsed = xdist.all_reduce_max(time.perf_counter() - t0)
     per_rank_ms = [round(v / args.steps, 4) for v in xdist.all_gather(float(dev_ms))]
     dev_ms = max(xdist.all_gather(float(dev_ms)))
+    # slab runs: how long each rank's compute stream sat waiting for its halo exchange after the interior launch (a lost
+    # overlap shows here; with a working one it is the cost of the two timing events).  The warm-up's share is small: W of W + K steps.
+    stats = ctx.comm_stats() if world > 1 else {"halo_wait_ms": 0.0, "halo_waits": 0}
+    halo_wait = xdist.all_gather([round(stats["halo_wait_ms"], 3), int(stats["halo_waits"])])
 
     # streaming-copy yardstick on the same device and buffers (after the timed region; f_1 is scratch now)
     copy_gbs = None
@@ -428,9 +453,13 @@ def main():
             "baseline_config": "configs[2]" if is_c2 else ("configs[3] (long axis = slowest array axis)" if (is_c3 and world == 8) else
                                                            ("configs[3]'s domain on fewer GPUs" if is_c3 else "other")),
             "decomposition": (f"{world} x-slab(s) of {'/'.join(str(slab_bounds(shape[0], r, world)[1]) for r in range(world))} planes, "
-                              + ("chain" if not periodic_x else "ring") + (" halo over RCCL" if transport == "rccl" else f" halo, NOT over RCCL — transport {transport}"))
+                              + ("chain" if not periodic_x else "ring") + (" halo over RCCL" if transport == "rccl" else f" halo, NOT over RCCL — transport {transport}")
+                              + (", all ranks on ONE device (rehearsal)" if os.environ.get("XLB_HIP_DEVICE", "").strip() else ""))
                              if world > 1 else "single GPU",
             "per_rank_ms_per_step": per_rank_ms,
+            # per rank: total ms the compute stream waited for halo exchanges (warm-up + timed steps), and how many exchanges
+            "halo_wait_ms": [h[0] for h in halo_wait] if world > 1 else None,
+            "halo_exchanges": [h[1] for h in halo_wait] if world > 1 else None,
         },
         "roofline": {
             "bound": "hbm",
@@ -446,6 +475,10 @@ def main():
             "hbm_gbs": None if traffic is None else round(traffic / (launch_ms * 1e-3) / 1e9, 1),
             "hbm_frac": None if traffic is None else round(traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "algorithmic_bytes_per_launch": int(b_alg * local_cells * spl),
+            # what a launch must move at the least: one read + one write of every population per LAUNCH (f(t+1) of a fused
+            # pair never reaches HBM), and the physical rate against that bound — `frac` above is the contract's effective figure
+            "fused_ideal_bytes_per_launch": int(b_alg * local_cells),
+            "frac_of_fused_ideal": round(b_alg * local_cells / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "kernel": kernel,
             "kernel_ms": round(step_ms, 4),  # device time per STEP (HIP events / K)
             "steps_per_launch": spl,

@@ -297,7 +297,19 @@ int xlbhip_comm_unique_id(void* out_id_bytes);     /* rank 0; broadcast by the h
 /* n_ranks == 1 with a non-NULL id creates a real one-rank RCCL communicator (self send/recv): used to
  * exercise the RCCL code path on a single GPU; with a NULL id the ghosts are refilled by device copies */
 int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_bytes, int periodic_x);
+/* The same exchange without RCCL: every rank exports the buffers it exchanges (hipIpcGetMemHandle) and PULLS the
+ * neighbours' planes with plane-sized hipMemcpyAsync on the communication stream — copy engines, no compute unit, no
+ * LDS ("or hipMemcpyPeerAsync ... over xGMI").  Processes are ordered by sequence counters in a host
+ * shared-memory control block /dev/shm/xlbhip-ipc-<token> (created by rank 0, unlinked as soon as every rank mapped
+ * it) that one-lane kernels post and poll; every wait is bounded by the option "ipc_timeout_ms" (a timed-out wait
+ * makes the next xlbhip_sync fail).  One node; the ranks may share a device.  `token`: letters / digits / '-' / '_',
+ * fresh per job (the host side broadcasts a random one).  Ranks must exchange the same buffers in the same order. */
+int xlbhip_comm_init_ipc(xlbhip_ctx* ctx, int rank, int n_ranks, const char* token, int periodic_x);
 int xlbhip_comm_destroy(xlbhip_ctx* ctx);
+/* Telemetry of the slab protocol: the time the compute stream spent waiting for the halo event after the interior
+ * launch, summed over `halo_waits` exchanges since the last reset (option "halo_telemetry", default on).  With a
+ * working overlap it is the event overhead only (a few microseconds per exchange).  Blocking. */
+int xlbhip_comm_stats(xlbhip_ctx* ctx, double* halo_wait_ms, int64_t* halo_waits, int reset);
 /* fill the ghost planes of f from the neighbours (blocking w.r.t. the compute stream order) */
 int xlbhip_halo_exchange(xlbhip_ctx* ctx, int lattice, xlbhip_field* f);
 /* the exchange a fused pair of steps needs (fields with 2 ghost planes): every population of the neighbours' edge

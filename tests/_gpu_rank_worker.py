@@ -1,8 +1,8 @@
 """Worker of tests/test_gpu_multirank.py: the full HIP slab path (per-slab masks from global indices,
 ghost planes, ring exchange, edge/interior kernels) on WORLD_SIZE ranks, checked against the
-single-domain oracle.  XLB_TEST_TRANSPORT=rccl uses the product transport (one GPU per rank);
-=host moves the ghost planes through gloo so that all ranks can share ONE GPU (XLB_HIP_DEVICE=0),
-which RCCL refuses ("Duplicate GPU detected")."""
+single-domain oracle.  XLB_TEST_TRANSPORT=rccl uses RCCL (one GPU per rank); =ipc the IPC-mapped
+peer copies on the communication stream (device-to-device, ranks may share ONE GPU: XLB_HIP_DEVICE=0);
+=host moves the ghost planes through the host, also on one GPU, which RCCL refuses ("Duplicate GPU detected")."""
 
 import os
 import sys
@@ -121,6 +121,13 @@ def main():
     if not good and rank == 0:
         print("mismatch: sphere channel across ranks", flush=True)
     ok &= good
+    if transport in ("ipc", "rccl") or xdist.transport() in ("ipc", "rccl"):
+        # device-side transports run the native slab protocol: the overlapped runs above timed the compute stream's halo waits
+        stats = ctx.comm_stats()
+        good = stats["halo_waits"] > 0
+        if not good and rank == 0:
+            print(f"telemetry: {stats}", flush=True)
+        ok &= good
     tot = xdist.all_reduce_sum(0.0 if ok else 1.0)
     if rank == 0:
         print("GPU_SLAB_OK" if tot == 0 else "GPU_SLAB_MISMATCH")

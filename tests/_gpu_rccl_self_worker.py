@@ -23,6 +23,9 @@ def main():
     init_hip("D3Q19")
     ctx = get_context()
     ctx.comm_init(0, 1, _lib.comm_unique_id())
+    # the all-reduce that decides "pairs or single steps" for all ranks (comm_all_min) had never executed —
+    # with one rank it is skipped; this option sends it through ncclAllReduce on the one-rank communicator too
+    ctx.set_option("comm_self_test", 1)
     ok = True
     # (12, 10, 16): single-step kernel with one or two ghost planes; (20, 16, 64): two-step kernel, depth-2 exchange
     for shape, halo, fuse2 in (((12, 10, 16), 1, 1), ((12, 10, 16), 2, 1), ((20, 16, 64), 2, 2)):
@@ -43,6 +46,10 @@ def main():
             if not good:
                 print(f"mismatch: shape {shape} halo {halo} fuse2 {fuse2} overlap {overlap}", flush=True)
             ok &= good
+    stats = ctx.comm_stats()
+    if not (stats["halo_waits"] > 0 and stats["halo_wait_ms"] >= 0.0):  # the overlapped runs above timed their halo waits
+        print(f"telemetry: {stats}", flush=True)
+        ok = False
     print("RCCL_SELF_OK" if ok else "RCCL_SELF_MISMATCH")
     sys.exit(0 if ok else 1)
 

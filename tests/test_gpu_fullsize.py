@@ -210,3 +210,71 @@ def test_config3_domain_on_one_gpu_matches_the_cube_near_its_walls():
         for x in (2001, 2047, 2048, 3000):
             assert np.array_equal(mid[(x, l)], mid[(2000, l)]), (x, l)
     assert any(np.abs(got[nx][("lo", 3, l)] - got[nx][("lo", 3, l)][0, 0]).max() > 0 for l in pops)  # not a trivial (uniform) comparison
+
+
+def hull_masks(shape, lat, lid_id, walls_id):
+    """The masks of the reference drivers' cavity (mlups_3d.py:193-204) written down directly from what the JAX masker produces
+    for hull-only BCs (missing[l, x] <=> x - c_l lies outside the box, for EVERY cell; bc_mask = lid on the
+    top face without its edges, walls on the rest of the hull) — O(N) NumPy, affordable at 512^3 where orc.build_masks' padded rolls
+    are not.  Checked against orc.build_masks at a small size by the caller."""
+    nx, ny, nz = shape
+    bm = np.zeros((1, nx, ny, nz), np.uint8)
+    b = bm[0]
+    b[0], b[-1], b[:, 0], b[:, -1], b[:, :, 0], b[:, :, -1] = (walls_id,) * 6
+    b[1:-1, 1:-1, -1] = lid_id
+    mm = np.zeros((lat.q, nx, ny, nz), bool)
+    for l in range(lat.q):
+        for axis, n in enumerate(shape):
+            c = int(lat.c[axis, l])
+            if c:
+                idx = [slice(None)] * 3
+                idx[axis] = 0 if c > 0 else n - 1  # x - c < 0 at x = 0 for c = +1; x - c > n - 1 at x = n - 1 for c = -1
+                mm[(l,) + tuple(idx)] = True
+    return bm, mm
+
+
+CASES_FULL_ORACLE = [(512, HalfwayBounceBackBC, 4, "tile"), (512, FullwayBounceBackBC, 4, "tile"), (256, HalfwayBounceBackBC, 12, "rest")]
+
+
+@pytest.mark.parametrize("n, walls_cls, steps, start", CASES_FULL_ORACLE)
+def test_cavity_fullsize_against_the_c_oracle(n, walls_cls, steps, start):
+    """BASELINE configs[2] at FULL size, compared DIRECTLY with the checker: oracle/lbm_ref.c — the plain-C
+    restatement of nse_stepper.py:237-282, bit-identical to the NumPy oracle (tests/test_oracle_c.py) — runs the 512^3 lid-driven
+    cavity with halfway and with fullway walls on the host's cores, the HIP stepper runs it through `stepper.run` with default
+    options (the two-step kernel), and ALL 19 x n^3 populations must be equal bit for bit.  "tile": the start is a perturbed
+    equilibrium (a 64^3 pattern tiled over the box), so every cell — every wall cell, every corner — carries a non-trivial state
+    from step one; "rest": the drivers' own start f = w, 12 steps at 256^3."""
+    from oracle import lbm_ref
+
+    shape = (n, n, n)
+    grid, bcs, lat, obcs = hip_cavity_3d(shape, walls_cls)
+    # masks: analytic hull masks, pinned to the oracle's masker at 16^3
+    s_bm, s_mm = hull_masks((16, 16, 16), lat, bcs[0].id, bcs[1].id)
+    o_small = orc.cavity_3d(16, obcs[1].kind)
+    remap = {o_small[2][0].id: bcs[0].id, o_small[2][1].id: bcs[1].id}
+    r_bm, r_mm = orc.build_masks((16, 16, 16), lat, o_small[2])
+    from _util import remap_ids
+
+    assert np.array_equal(s_bm, remap_ids(r_bm, remap)) and np.array_equal(s_mm, r_mm)
+    o_bm, o_mm = hull_masks(shape, lat, bcs[0].id, bcs[1].id)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert np.array_equal(bc_mask.numpy(), o_bm)
+    assert np.array_equal(missing_mask.numpy(), o_mm.astype(np.uint8))
+    if start == "tile":
+        t = 64
+        f_np = np.tile(orc.perturbed_init((t, t, t), lat, seed=77), (1, n // t, n // t, n // t))
+        f_0.assign(f_np)
+    else:
+        f_np = np.ascontiguousarray(np.broadcast_to(orc.initialize_eq((1, 1, 1), lat).reshape(19, 1, 1, 1), (19, n, n, n)).astype(np.float32))
+    if n == 512:
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)  # the kernel the bench line is quoted on
+    a, b = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.0, steps)
+    got = a.numpy()
+    for fld in (f_0, f_1, bc_mask, missing_mask):
+        fld.free()
+    exp = lbm_ref.run(f_np, o_bm, o_mm, obcs, 1.0, lat, steps)
+    del f_np
+    assert got.shape == exp.shape == (19, n, n, n) and got.dtype == exp.dtype == np.float32
+    assert np.array_equal(got, exp)
+    assert float(np.abs(exp[:, 1:-1, 1:-1, -2] - exp[:, 1:2, 1:2, 1:2].reshape(19, 1, 1)).max()) > 1e-4  # the lid drove the layer below it

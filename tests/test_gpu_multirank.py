@@ -2,6 +2,8 @@
   * two ranks sharing device 0 with the host-staged (gloo) halo transport — everything of the
     multi-rank path except the RCCL calls: per-slab masks from global indices, ghost planes,
     uneven slabs, periodic ring;
+  * two and three ranks sharing device 0 with the IPC transport — device-to-device ghost planes on the communication
+    stream, the native protocol end to end (overlap, pairing vote, meta planes), only the wire is not xGMI;
   * one rank with a REAL RCCL communicator (self send/recv) — the RCCL calls, the communication
     stream and the interior/edge overlap, minus the wire;
   * two ranks over RCCL proper: runs when RCCL accepts the device set, skipped on "Duplicate GPU".
@@ -33,6 +35,17 @@ def test_ranks_sharing_one_gpu_host_staged_halo(world):
     assert "GPU_SLAB_OK" in out.stdout
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_ipc_halo(world):
+    """The device-to-device transport that does not need RCCL: hipIpc-mapped neighbour fields pulled
+    with copies on the communication stream, ordered by counters in host shared memory — with 2 and 3 ranks on ONE GPU
+    the whole native slab protocol runs: depth-1 and depth-2 exchanges, chain ends, uneven slabs, overlap on / off, the
+    collective pairing vote, the meta-plane exchange.  Bit-exact against the single-domain oracle."""
+    out = torchrun("_gpu_rank_worker.py", world, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="ipc")
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "GPU_SLAB_OK" in out.stdout
+
+
 def test_one_rank_real_rccl_self_exchange():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_rccl_self_worker.py")], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
@@ -41,15 +54,15 @@ def test_one_rank_real_rccl_self_exchange():
 
 
 def test_two_ranks_rccl_or_host_falls_back_together():
-    """transport="rccl_or_host" (bench.py's default): on a one-GPU box RCCL refuses the second rank on the device, every rank hears about
-    it through the rendezvous, all of them switch to the host-staged transport and the run is still bit-identical to the single-domain
-    oracle.  (Where RCCL accepts the device set this is the RCCL run.)"""
+    """transport="auto" (bench.py's default; "rccl_or_host" is its round-2 name): on a one-GPU box RCCL refuses the second rank on the
+    device, every rank hears about it through the rendezvous, all of them move on to the next transport of the chain (ipc, then host)
+    and the run is still bit-identical to the single-domain oracle.  (Where RCCL accepts the device set this is the RCCL run.)"""
     out = torchrun("_gpu_rank_worker.py", 2, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="rccl_or_host")
     text = out.stdout + out.stderr
     assert out.returncode == 0, text[-3000:]
     assert "GPU_SLAB_OK" in out.stdout
-    if "falls back to the host-staged halo transport" in text:
-        assert "RCCL communicator failed" in text
+    if "falls back to" in text:
+        assert "halo transport 'rccl' failed" in text and "every rank falls back to 'ipc'" in text
 
 
 def test_two_ranks_rccl():

@@ -94,7 +94,9 @@ SIGNATURES = {
     "xlbhip_run_any": [_p, _p, _p, _p, _p, _d, _i64, _i64, C.POINTER(C.c_int)],
     "xlbhip_comm_unique_id": [_p],
     "xlbhip_comm_init": [_p, _i, _i, _p, _i],
+    "xlbhip_comm_init_ipc": [_p, _i, _i, C.c_char_p, _i],
     "xlbhip_comm_destroy": [_p],
+    "xlbhip_comm_stats": [_p, C.POINTER(C.c_double), C.POINTER(_i64), _i],
     "xlbhip_halo_exchange": [_p, _i, _p],
     "xlbhip_halo_exchange_wide": [_p, _i, _p],
     "xlbhip_step2_eligible": [_p, _p, _p, _p, _p],
@@ -203,6 +205,20 @@ class Context:
         buf = C.create_string_buffer(bytes(id_bytes), UNIQUE_ID_BYTES) if id_bytes is not None else None
         check(load().xlbhip_comm_init(self.handle, int(rank), int(n_ranks), buf, 1 if periodic_x else 0))
         self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def comm_init_ipc(self, rank, n_ranks, token, periodic_x=True):
+        """Join the IPC halo transport of the job named by ``token`` (xlbhip_comm_init_ipc)."""
+        check(load().xlbhip_comm_init_ipc(self.handle, int(rank), int(n_ranks), str(token).encode(), 1 if periodic_x else 0))
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def comm_destroy(self):
+        check(load().xlbhip_comm_destroy(self.handle))
+
+    def comm_stats(self, reset=False):
+        """{"halo_wait_ms": ..., "halo_waits": ...}: time the compute stream waited for halo exchanges (xlbhip_comm_stats)."""
+        ms, n = C.c_double(), _i64()
+        check(load().xlbhip_comm_stats(self.handle, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return {"halo_wait_ms": ms.value, "halo_waits": n.value}
 
     def close(self):
         if self._h:

@@ -134,7 +134,10 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   xlbhip_ctx* c = new xlbhip_ctx();
   c->device = device;
   XLB_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  XLB_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  // the halo stream outranks the compute stream: its small kernels / copies must not queue behind the interior launch
+  int prio_low = 0, prio_high = 0;
+  XLB_HIP(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  XLB_HIP(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, prio_high));
   XLB_HIP(hipEventCreate(&c->ev_a));
   XLB_HIP(hipEventCreate(&c->ev_b));
   XLB_HIP(hipEventCreateWithFlags(&c->ev_edge, hipEventDisableTiming));
@@ -164,6 +167,10 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fast_bgk"] = 0;         // two-step kernel: 1 = tolerance-graded fast BGK body (rounding-level differences; +2-4 %)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
+  c->opts["halo_telemetry"] = 1;   // slab runs: time the compute stream's wait for the halo event (xlbhip_comm_stats)
+  c->opts["ipc_timeout_ms"] = 60000;  // ipc transport: bound of every device-side / host-side wait for a neighbour
+  c->opts["halo_skip"] = 0;        // 1: MEASUREMENT ONLY — the slab protocol's launches without moving any ghost plane (wrong results)
+  c->opts["comm_self_test"] = 0;   // 1: a one-rank RCCL communicator also runs the all-reduce of comm_all_min (tests)
   *out = c;
   return 0;
 }
@@ -177,6 +184,10 @@ int xlbhip_destroy(xlbhip_ctx* c) {
   (void)hipEventDestroy(c->ev_b);
   (void)hipEventDestroy(c->ev_edge);
   (void)hipEventDestroy(c->ev_halo);
+  for (int i = 0; i < xlbhip_ctx::WAIT_RING; ++i) {
+    if (c->ev_w0[i]) (void)hipEventDestroy(c->ev_w0[i]);
+    if (c->ev_w1[i]) (void)hipEventDestroy(c->ev_w1[i]);
+  }
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->comm_stream);
   delete c;
@@ -187,7 +198,7 @@ int xlbhip_sync(xlbhip_ctx* c) {
   XLB_REQUIRE(c, "ctx is null");
   XLB_HIP(hipStreamSynchronize(c->comm_stream));
   XLB_HIP(hipStreamSynchronize(c->stream));
-  return 0;
+  return comm_check(c);
 }
 
 int xlbhip_device_info(xlbhip_ctx* c, char* name, int name_len, int* cus, uint64_t* hbm) {
@@ -272,6 +283,8 @@ int xlbhip_field_destroy(xlbhip_field* f) {
   if (!f) return 0;
   (void)hipSetDevice(f->ctx->device);
   (void)hipStreamSynchronize(f->ctx->stream);
+  (void)hipStreamSynchronize(f->ctx->comm_stream);
+  comm_forget_buffer(f->ctx, f->base);
   (void)hipFree(f->base);
   delete f;
   return 0;
@@ -1258,6 +1271,37 @@ static int step_twice_edge_ext(xlbhip_stepper* s, StepLaunch p, const xlbhip_fie
   return outflow_aux(s, s->scratch, dst, bcm, miss);
 }
 
+// the compute stream waits for the halo exchange; with the telemetry on, the wait is bracketed by two timing events
+static int harvest_wait(xlbhip_ctx* c, int slot) {
+  if (!c->wait_used[slot]) return 0;
+  float ms = 0.f;
+  XLB_HIP(hipEventSynchronize(c->ev_w1[slot]));
+  XLB_HIP(hipEventElapsedTime(&ms, c->ev_w0[slot], c->ev_w1[slot]));
+  c->halo_wait_ms += ms;
+  c->halo_waits += 1;
+  c->wait_used[slot] = false;
+  return 0;
+}
+
+static int wait_for_halo(xlbhip_ctx* c) {
+  if (!opt(c, "halo_telemetry", 1)) {
+    XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    return 0;
+  }
+  const int slot = c->wait_head;
+  c->wait_head = (c->wait_head + 1) % xlbhip_ctx::WAIT_RING;
+  if (int rc = harvest_wait(c, slot)) return rc;  // (32 exchanges old: long complete)
+  if (!c->ev_w0[slot]) {
+    XLB_HIP(hipEventCreate(&c->ev_w0[slot]));
+    XLB_HIP(hipEventCreate(&c->ev_w1[slot]));
+  }
+  XLB_HIP(hipEventRecord(c->ev_w0[slot], c->stream));
+  XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  XLB_HIP(hipEventRecord(c->ev_w1[slot], c->stream));
+  c->wait_used[slot] = true;
+  return 0;
+}
+
 // two steps in one pass (a -> scratch-free: src -> dst holds f(t+2)); caller checked eligibility
 static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                       double omega) {
@@ -1294,7 +1338,7 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   p.x_count = src->nx - 4;
   p.x_segments = fuse2_segments(s, p);
   if (int rc = launch_step2(s, p)) return rc;
-  XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+  if (int rc = wait_for_halo(c)) return rc;
   p.x_segments = 1;
   p.x_count = 2;
   p.x_begin = 0;
@@ -1371,7 +1415,10 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
   xlbhip_ctx* c = s->ctx;
   const size_t cells = bcm->cells_with_halo();
   if (s->meta_cells != cells) {
-    if (s->meta) XLB_HIP(hipFree(s->meta));
+    if (s->meta) {
+      comm_forget_buffer(c, s->meta);
+      XLB_HIP(hipFree(s->meta));
+    }
     s->meta = nullptr;
     XLB_HIP(hipMalloc(&s->meta, cells * sizeof(uint32_t)));
     s->meta_cells = cells;
@@ -1488,7 +1535,7 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
     p.x_begin = 1;
     p.x_count = src->nx - 2;
     if (int rc = launch_any(s, p)) return rc;
-    XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
+    if (int rc = wait_for_halo(c)) return rc;
     p.x_begin = 0;
     p.x_count = 1;
     if (int rc = launch_any(s, p)) return rc;
@@ -1721,7 +1768,10 @@ int xlbhip_stepper_destroy(xlbhip_stepper* s) {
   if (s->dist_keys) (void)hipFree(s->dist_keys);
   if (s->dist_vals) (void)hipFree(s->dist_vals);
   if (s->scratch) xlbhip_field_destroy(s->scratch);
-  if (s->meta) (void)hipFree(s->meta);
+  if (s->meta) {
+    comm_forget_buffer(s->ctx, s->meta);
+    (void)hipFree(s->meta);
+  }
   if (s->tile_order) (void)hipFree(s->tile_order);
   drop_clean_cache(s);
   delete s;
@@ -1817,6 +1867,19 @@ int xlbhip_run_timed(xlbhip_stepper* s, xlbhip_field* a, xlbhip_field* b, const 
   XLB_HIP(hipEventRecord(c->ev_b, c->stream));
   XLB_HIP(hipEventSynchronize(c->ev_b));
   XLB_HIP(hipEventElapsedTime(ms, c->ev_a, c->ev_b));
+  return 0;
+}
+
+int xlbhip_comm_stats(xlbhip_ctx* c, double* halo_wait_ms, int64_t* halo_waits, int reset) {
+  XLB_REQUIRE(c, "ctx is null");
+  for (int i = 0; i < xlbhip_ctx::WAIT_RING; ++i)
+    if (int rc = harvest_wait(c, i)) return rc;
+  if (halo_wait_ms) *halo_wait_ms = c->halo_wait_ms;
+  if (halo_waits) *halo_waits = c->halo_waits;
+  if (reset) {
+    c->halo_wait_ms = 0.0;
+    c->halo_waits = 0;
+  }
   return 0;
 }
 

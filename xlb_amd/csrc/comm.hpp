@@ -1,4 +1,4 @@
-// Slab halo exchange (ring over the slowest spatial axis) — RCCL send/recv, loaded lazily.
+// Slab halo exchange (ring over the slowest spatial axis) — RCCL send/recv (loaded lazily) or IPC-mapped peer copies.
 #pragma once
 #include "common.hpp"
 
@@ -12,4 +12,8 @@ int plane_exchange_on(xlbhip_ctx* c, void* base, size_t elem_bytes, int nx, int 
 // MIN of `value` over the ranks of the context's communicator (blocking; `*out = value` without one)
 int comm_all_min(xlbhip_ctx* c, int value, int* out);
 int comm_ranks(const xlbhip_ctx* c);
+// ipc transport: non-zero (error set) when a device-side wait of this rank timed out since the last check
+int comm_check(xlbhip_ctx* c);
+// an allocation that may have been exported is about to be freed
+void comm_forget_buffer(xlbhip_ctx* c, const void* alloc_base);
 }  // namespace xlb

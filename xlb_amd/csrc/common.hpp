@@ -54,6 +54,14 @@ struct xlbhip_ctx {
   hipStream_t comm_stream = nullptr;  // halo exchange stream
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipEvent_t ev_edge = nullptr, ev_halo = nullptr;
+  // telemetry of the slab protocol: how long the compute stream sat at the halo event after the interior launch
+  // (a lost overlap shows up here).  A ring of timing-event pairs, harvested when a slot comes round again.
+  static const int WAIT_RING = 32;
+  hipEvent_t ev_w0[WAIT_RING] = {}, ev_w1[WAIT_RING] = {};
+  bool wait_used[WAIT_RING] = {};
+  int wait_head = 0;
+  double halo_wait_ms = 0.0;
+  int64_t halo_waits = 0;
   std::map<std::string, int64_t> opts;
   xlb::Comm* comm = nullptr;
   int compute_units = 0;

@@ -3,9 +3,9 @@
 Reference semantics: xlb/distribute/distribute.py:18-48 — the domain is split along the
 slowest spatial axis (array axis 1) and, every step, the populations with c_x = +1 / -1 of the
 slab faces travel to the right / left ring neighbour (``rightPerm`` / ``leftPerm``, periodic
-wrap included).  Here each rank keeps ONE ghost x-plane per side, filled before the pull by
-RCCL ``ncclSend``/``ncclRecv`` on a dedicated HIP stream (csrc/comm.cpp) and overlapped with the
-update of the planes that do not touch a ghost (csrc/api.hip: step_once).
+wrap included).  Here each rank keeps ghost x-planes, filled before the pull on a dedicated HIP stream
+(csrc/comm.cpp) — by RCCL ``ncclSend``/``ncclRecv``, or by copy-engine pulls out of the neighbours' IPC-mapped
+fields — and overlapped with the update of the planes that do not touch a ghost (csrc/api.hip: step_once, step_twice).
 
 Process-group plumbing (rendezvous, unique-id broadcast, barriers, small reductions, gathering
 results for tests) goes through ``rendezvous.py`` — a star of plain TCP sockets with rank 0 as the
@@ -28,6 +28,116 @@ def _env_int(name, default):
     return int(v) if v else default
 
 
+_TRANSPORT_CHAINS = {
+    "rccl": ["rccl"],
+    "ipc": ["ipc"],
+    "host": ["host"],
+    "rccl_or_host": ["rccl", "ipc", "host"],  # (round-2 name of "auto")
+    "auto": ["rccl", "ipc", "host"],
+    "ipc_or_host": ["ipc", "host"],
+}
+
+
+def _try_transport(name, ctx, rdv, rank, world, periodic_x):
+    """Bring device transport `name` up on this rank and prove it with a small exchange; returns None or the reason it failed.
+    Collective (the same calls in the same order on every rank, whatever fails where)."""
+    err = None
+    if name == "rccl":
+        uid = None
+        if rank == 0:
+            try:
+                uid = _lib.comm_unique_id()
+            except Exception as e:  # noqa: BLE001 (whatever RCCL / the loader raises: the other ranks must hear about it)
+                err = e
+        uid = rdv.broadcast(uid, src=0)
+        if uid is not None:
+            try:
+                ctx.comm_init(rank, world, uid, periodic_x=periodic_x)
+            except Exception as e:  # noqa: BLE001
+                err = e
+        elif err is None:
+            err = RuntimeError("rank 0 could not create the RCCL unique id")
+    else:  # "ipc"
+        # a fresh random name for the control block in /dev/shm, drawn by rank 0
+        token = rdv.broadcast(os.urandom(12).hex() if rank == 0 else None, src=0)
+        same_host = len({tuple(v) for v in rdv.all_gather(_host_identity())}) == 1
+        if not same_host:
+            err = RuntimeError("the ipc transport needs every rank on one node")
+        else:
+            try:
+                ctx.comm_init_ipc(rank, world, token, periodic_x=periodic_x)
+            except Exception as e:  # noqa: BLE001
+                err = e
+    # every rank must have a communicator before anyone exchanges (a rank without one would leave the others waiting)
+    up = [r for r in rdv.all_gather(None if err is None else f"rank {rank}: {err}") if r]
+    if not up:
+        probe = None
+        try:
+            probe = _lib.Field(ctx, 19, _PROBE_SHAPE, _lib.F32, halo=2)
+            _verify_exchange(ctx, probe, rank, world, periodic_x)
+        except Exception as e:  # noqa: BLE001
+            err = e
+        up = [r for r in rdv.all_gather(None if err is None else f"rank {rank}: {name} self-check: {err}") if r]
+        if probe is not None:  # (only now: the neighbours have finished reading it)
+            probe.free()
+    if up:
+        try:
+            ctx.comm_destroy()
+        except Exception:  # noqa: BLE001
+            pass
+        ctx.rank, ctx.n_ranks = 0, 1
+        return up[0]
+    return None
+
+
+def _host_identity():
+    import socket
+
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return [socket.gethostname(), boot]
+
+
+_PROBE_SHAPE = (4, 8, 64)
+
+
+def _verify_exchange(ctx, f, rank, world, periodic_x):
+    """One depth-2 exchange of a small rank-stamped field through the transport that was just set up, ghost planes checked
+    against what the neighbours must have sent: a transport that comes up but moves wrong bytes is not trusted with a run."""
+    (nx, ny, nz), q = _PROBE_SHAPE, 19
+
+    def stamp(r, l, x):  # value of every cell of interior plane x, population l, on rank r
+        return float(1 + r * 1000 + l * 10 + x)
+
+    host = np.empty((q, nx, ny, nz), np.float32)
+    for l in range(q):
+        for x in range(nx):
+            host[l, x] = stamp(rank, l, x)
+    f.assign(host)
+    ctx.sync()
+    _lib.check(_lib.load().xlbhip_halo_exchange_wide(ctx.handle, _lib.D3Q19, f.handle))
+    ctx.sync()
+    c_x = _lib.lattice_info(_lib.D3Q19)[2][0]
+    left, right = (rank - 1) % world, (rank + 1) % world
+    has_left, has_right = periodic_x or rank > 0, periodic_x or rank + 1 < world
+    for l in range(q):
+        checks = []
+        if has_left:
+            checks.append((1, stamp(left, l, nx - 1)))        # ghost -1  <- left neighbour's last plane, every population
+            if c_x[l] == 1:
+                checks.append((0, stamp(left, l, nx - 2)))    # ghost -2  <- the plane behind it, populations moving right
+        if has_right:
+            checks.append((nx + 2, stamp(right, l, 0)))
+            if c_x[l] == -1:
+                checks.append((nx + 3, stamp(right, l, 1)))
+        for storage_plane, want in checks:
+            got = f.get_plane(l, storage_plane)
+            if not np.all(got == np.float32(want)):
+                raise RuntimeError(f"ghost plane {storage_plane} of population {l} holds {got.flat[0]!r}, expected {want!r}")
+
+
 def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl"):
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (as set by
     ``python -m torch.distributed.run`` or by ``bench.py``'s launcher).  Single-process jobs return (0, 1).
@@ -35,10 +145,14 @@ def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl")
     ``periodic_x=False``: the global x axis ends in walls, so the ring is a chain — rank 0 and rank N-1
     exchange nothing (a walled cavity never pulls across that face).
 
-    ``transport``: "rccl" (ghost planes over RCCL send / recv; an error if the communicator cannot be built), "host" (through host
-    memory and the rendezvous hub: debugging, several ranks on one GPU), "rccl_or_host" (RCCL, and if building the communicator FAILS on
-    any rank every rank falls back to "host" — decided collectively, said on stderr, reported by ``transport()``; a hang inside RCCL
-    cannot be caught)."""
+    ``transport``: how ghost planes travel.
+      * "rccl": RCCL send / recv (csrc/comm.cpp); an error if the communicator cannot be built or fails its self-check;
+      * "ipc": the neighbours' fields mapped through HIP IPC and pulled with copy-engine copies on the communication
+        stream, ordered by counters in a host shared-memory block (one node; the ranks may share a device);
+      * "host": through host memory and the rendezvous (debugging; orders of magnitude slower);
+      * "auto" (= "rccl_or_host", the round-2 name): RCCL, else ipc, else host — a transport that FAILS to come up or
+        fails its self-check on any rank is dropped by all ranks together, said on stderr, reported by ``transport()``.
+        A hang inside RCCL cannot be caught."""
     rank, world = _env_int("RANK", 0), _env_int("WORLD_SIZE", 1)
     _state["rank"], _state["world"] = rank, world
     if world == 1:
@@ -51,45 +165,37 @@ def init_process_group(periodic_x=True, init_device_comm=True, transport="rccl")
     _state["periodic_x"] = bool(periodic_x)
     if init_device_comm:
         ctx = get_context()  # device = XLB_HIP_DEVICE or LOCAL_RANK (default_config._pick_device)
-        if transport not in ("rccl", "host", "rccl_or_host"):
+        if transport not in _TRANSPORT_CHAINS:
             raise ValueError(f"unknown halo transport {transport!r}")
-        _state["transport"] = "host" if transport == "host" else "rccl"
-        if transport != "host":
-            err = None
-            uid = None
+        chain = _TRANSPORT_CHAINS[transport]
+        chosen, why = None, []
+        for name in chain:
+            if name == "host":
+                chosen = "host"
+                break
+            reason = _try_transport(name, ctx, rdv, rank, world, periodic_x)
+            if reason is None:
+                chosen = name
+                break
+            why.append(f"{name}: {reason}")
+            if name == chain[-1]:
+                raise RuntimeError(f"halo transport {name!r} failed: {reason}")
             if rank == 0:
-                try:
-                    uid = _lib.comm_unique_id()
-                except Exception as e:  # noqa: BLE001 (whatever RCCL / the loader raises: the other ranks must hear about it)
-                    err = e
-            uid = rdv.broadcast(uid, src=0)
-            if uid is not None:
-                try:
-                    ctx.comm_init(rank, world, uid, periodic_x=periodic_x)
-                except Exception as e:  # noqa: BLE001
-                    err = e
-            elif err is None:
-                err = RuntimeError("rank 0 could not create the RCCL unique id")
-            reasons = [r for r in rdv.all_gather(None if err is None else f"rank {rank}: {err}") if r]
-            if reasons:
-                if transport == "rccl":
-                    raise err if err is not None else RuntimeError("RCCL communicator failed on another rank: " + reasons[0])
                 import sys
 
-                if rank == 0:
-                    print(f"xlb_amd.distribute: RCCL communicator failed ({reasons[0]}); every rank falls back to the host-staged halo transport",
-                          file=sys.stderr, flush=True)
-                _state["transport"] = "host (fallback: " + reasons[0][:200] + ")"
-        if _state["transport"] != "rccl":
-            # ghost planes travel through host memory and the rendezvous hub (HostStagedHalo): the debugging transport — it lets
-            # several ranks share ONE GPU, which RCCL refuses ("Duplicate GPU detected") — and the fallback of "rccl_or_host"
+                print(f"xlb_amd.distribute: halo transport {name!r} failed ({reason}); every rank falls back to {chain[chain.index(name) + 1]!r}",
+                      file=sys.stderr, flush=True)
+        _state["transport"] = chosen if not why else f"{chosen} (fallback: {'; '.join(w[:200] for w in why)})"
+        if chosen == "host":
+            # ghost planes travel through host memory and the rendezvous hub (HostStagedHalo): the debugging transport and the
+            # last resort of "auto"
             ctx.rank, ctx.n_ranks = rank, world
             ctx.set_option("external_halo", 1)
     return rank, world
 
 
 def transport():
-    """The halo transport in use: "rccl", "host", or "host (fallback: <why RCCL failed>)"; None before init_process_group."""
+    """The halo transport in use: "rccl", "ipc", "host", or e.g. "ipc (fallback: rccl: <why it failed>)"; None before init_process_group."""
     return _state.get("transport")
 
 
