@@ -298,8 +298,9 @@ int xlbhip_comm_unique_id(void* out_id_bytes);     /* rank 0; broadcast by the h
  * exercise the RCCL code path on a single GPU; with a NULL id the ghosts are refilled by device copies */
 int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_bytes, int periodic_x);
 /* The same exchange without RCCL: every rank exports the buffers it exchanges (hipIpcGetMemHandle) and PULLS the
- * neighbours' planes with plane-sized hipMemcpyAsync on the communication stream — copy engines, no compute unit, no
- * LDS ("or hipMemcpyPeerAsync ... over xGMI").  Processes are ordered by sequence counters in a host
+ * neighbours' planes on the communication stream — by one small copy kernel per exchange (option "ipc_copy" = 1, the
+ * default: 8 blocks per plane, no LDS) or by plane-sized hipMemcpyAsync calls (= 0: copy engines, no compute unit;
+ * "or hipMemcpyPeerAsync ... over xGMI").  Processes are ordered by sequence counters in a host
  * shared-memory control block /dev/shm/xlbhip-ipc-<token> (created by rank 0, unlinked as soon as every rank mapped
  * it) that one-lane kernels post and poll; every wait is bounded by the option "ipc_timeout_ms" (a timed-out wait
  * makes the next xlbhip_sync fail).  One node; the ranks may share a device.  `token`: letters / digits / '-' / '_',

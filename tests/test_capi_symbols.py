@@ -69,7 +69,8 @@ def test_lattice_tables_in_the_kernels_match_python_without_a_device():
         assert np.array_equal(cc[:, : vs._cc.shape[1]], vs._cc.astype(np.int32))
 
 
-def test_two_step_kernel_does_not_spill(tmp_path):
+@pytest.mark.parametrize("source", ["step2_d3q19.hip", "step2_d3q19_strips.hip"])
+def test_two_step_kernel_does_not_spill(tmp_path, source):
     """k_step2 counts its outstanding vector-memory operations by hand (a counted s_waitcnt vmcnt(N) behind inline-asm loads,
     step2_kernel.hpp): a register spill adds scratch loads/stores the count does not know about and may copy a register
     an asm load is still writing.  The kernel sits close to the SGPR/VGPR limits, so guard the compiled result."""
@@ -81,7 +82,7 @@ def test_two_step_kernel_does_not_spill(tmp_path):
         pytest.skip("hipcc not available")
     out = tmp_path / "step2.s"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", f"-I{os.path.join(ROOT, 'include')}", "-S",
-           "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "xlb_amd", "csrc", "step2_d3q19.hip")]
+           "--cuda-device-only", "-o", str(out), os.path.join(ROOT, "xlb_amd", "csrc", source)]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
     text = out.read_text()
     assert text.count("k_step2") > 0

@@ -48,6 +48,28 @@ def test_fast_kbc_within_tolerance_and_exact_option_is_bit_exact(policy):
         assert err > 0.0
 
 
+def test_fast_kbc_300_steps_at_omega_1p9_within_tolerance():
+    """VERDICT r02 item 4's gate for the fp32 gamma reduction (cell.hpp COLL_G32: with a store type narrower than fp64 the two
+    scalar products behind gamma run in fp32): BASELINE configs[4]'s set-up — D3Q27 KBC, fp64 compute / fp32 store, omega = 1.9 —
+    on 24^3 for 300 steps stays within the north-star tolerance of the oracle (kbc.py:58-94)."""
+    vs, pp = init_hip("D3Q27", "FP64FP32")
+    lat = orc.Lattice("D3Q27")
+    shape, omega, steps = (24, 24, 24), 1.9, 300
+    f_np = orc.perturbed_init(shape, lat, "FP64FP32", seed=29, amp_rho=0.02, amp_u=0.03)
+    bm, mm = orc.build_masks(shape, lat, [])
+    exp = orc.run(f_np, bm, mm, [], omega, lat, steps, "FP64FP32", "KBC")
+    grid = grid_factory(shape)
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=[], collision_type="KBC")
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    f_0.assign(f_np)
+    f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, steps)
+    got = f_0.numpy()
+    err = float(np.abs(got.astype(np.float64) - exp.astype(np.float64)).max())
+    print(f"fast fp64 KBC (fp32 gamma reduction), 300 steps: max |f - oracle| = {err:.3e}, bit-identical cells {np.mean(got == exp):.4f}")
+    assert err <= TOL
+    assert float(np.abs(exp - f_np).max()) > 1e-4  # the state really evolved
+
+
 def test_fast_kbc_golden_config5_twin():
     """The committed 12^3 golden vector of configs[4] (D3Q27 KBC FP64FP32) at the default (fast) setting."""
     g = golden("d3q27_kbc_12")

@@ -468,3 +468,59 @@ def test_two_step_y_wall_redirect_regression(faces):
     finally:
         ctx.set_option("fuse2", 1)
         ctx.set_option("fuse2_xseg", 0)
+
+
+@pytest.mark.parametrize("walls_cls", [None, HalfwayBounceBackBC, FullwayBounceBackBC])
+@pytest.mark.parametrize("halo", [0, 2])
+def test_two_step_strip_buffers_follow_the_fields(walls_cls, halo):
+    """Strip buffers of the two-step kernel (step2_kernel.hpp; round 3): phase A takes the halo columns of its grown tile from
+    the source field's strips, phase B writes the destination's.  The strips are a cache of the field: whatever else writes
+    a field must invalidate them.  One scenario exercises every way in — strips built from the field (k_build_strips),
+    strips written by phase B and re-read, a single step in between (k_step writes the field, not its strips), a host upload
+    into a field whose strips were valid, a run with the strips switched off and on again, the wide (nz = 128: two tile
+    columns, so the halo columns really come from ANOTHER tile's cells) and the slab layout — against the oracle, bit for bit."""
+    shape = (20, 16, 128)
+    cfg = {"halo": halo} if halo else None
+    if walls_cls is None:
+        vs, pp = init_hip("D3Q19")
+        lat = orc.Lattice("D3Q19")
+        grid = grid_factory(shape, backend_config=cfg)
+        bcs, obcs = [], []
+        o_bm, o_mm = np.zeros((1,) + shape, np.uint8), np.zeros((lat.q,) + shape, bool)
+    else:
+        grid, bcs, lat, obcs = hip_cavity_3d(shape, walls_cls, backend_config=cfg)
+        o_bm, o_mm = orc.build_masks(shape, lat, obcs)
+    ctx = get_context()
+    try:
+        ctx.set_option("fuse2", 2)
+        assert ctx.get_option("fuse2_strips") == 1  # the default
+        stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+        f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+        f_np = orc.perturbed_init(shape, lat, seed=41)
+        f_0.assign(f_np)
+        state = f_np
+        # 7 steps: strips built from f_0, written by three passes and re-read, then one single step
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 7)
+        state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 7)
+        assert np.array_equal(f_0.numpy(), state)
+        # the single step left a field whose strips are stale: the next pairs must rebuild them
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 4)
+        state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 4)
+        assert np.array_equal(f_0.numpy(), state)
+        # a host upload into a field with valid strips
+        state = orc.perturbed_init(shape, lat, seed=43)
+        f_0.assign(state)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 2)
+        state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 2)
+        assert np.array_equal(f_0.numpy(), state)
+        # strips off for a run (the fields change, their strips do not), then on again
+        ctx.set_option("fuse2_strips", 0)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 2)
+        ctx.set_option("fuse2_strips", 1)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 4)
+        state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 6)
+        assert np.array_equal(f_0.numpy(), state)
+    finally:
+        ctx.set_option("fuse2", 1)
+        ctx.set_option("fuse2_strips", 1)

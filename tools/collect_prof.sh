@@ -1,6 +1,17 @@
 #!/bin/bash
-# tools/collect_prof.sh <gpurun_out/prof_TAG> <profiles/rNN/NAME>: the judged artefacts of one tools/profile.sh run
+# tools/collect_prof.sh <gpurun_out/prof_TAG> <profiles/rNN/NAME>: the judged artefacts of one tools/profile.sh run.
+# The kernel-stats CSV must be THE one of the kernel-trace run the summary was computed from: profile.sh wipes its output
+# directory first, so exactly one exists; anything else is an error instead of a guess.
+set -e
 D=$1; N=$2
+mapfile -t stats < <(find $D/kt -name "*kernel_stats.csv")
+if [ ${#stats[@]} -ne 1 ]; then
+  echo "collect_prof.sh: expected exactly one *kernel_stats.csv under $D/kt, found ${#stats[@]}" >&2
+  exit 1
+fi
 cp $D/summary.md ${N}_summary.md
-f=$(find $D/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f ${N}_kernel_stats.csv
+cp ${stats[0]} ${N}_kernel_stats.csv
 grep -h '^{"metric"' $D/kt.log | tail -1 > ${N}_bench_under_rocprof.json
+# the kernel the summary names first must be in the CSV too (same instantiation, same run)
+k=$(grep -m1 -o '`k_step[^`]*`' ${N}_summary.md | tr -d '`' | cut -c1-60)
+grep -q -F "$k" ${N}_kernel_stats.csv || { echo "collect_prof.sh: '$k' of the summary is not in the kernel-stats CSV" >&2; exit 1; }

@@ -6,6 +6,9 @@ set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
+# a tag re-used across runs must not keep an earlier run's CSVs (a kernel_stats.csv of an older build ended up
+# beside a newer summary): every run starts from an empty directory
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace: the default bench command (200 steps, 10 warm-up) minus the CPU-baseline leg; counters: a shorter run

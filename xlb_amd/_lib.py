@@ -488,6 +488,14 @@ def _h(field):
     return field.handle
 
 
+def _hf(field):
+    """handle of a population field argument: one that was exported as a writable zero-copy alias may have been written by its
+    consumer, so what the library caches on its contents (the two-step kernel's strip buffer) is dropped first."""
+    if field._pinned:
+        field.touch()
+    return field.handle
+
+
 class Stepper:
     """Native stepper object (xlbhip_stepper_create)."""
 
@@ -529,26 +537,26 @@ class Stepper:
         check(load().xlbhip_stepper_set_smagorinsky(self._h, float(coef)))
 
     def step(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
-        check(load().xlbhip_step(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
+        check(load().xlbhip_step(self._h, _hf(f_src), _hf(f_dst), _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
 
     def step2_eligible(self, f_src, f_dst, bc_mask, missing_mask):
         return bool(load().xlbhip_step2_eligible(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask)))
 
     def step2(self, f_src, f_dst, bc_mask, missing_mask, omega, timestep):
         """Two steps in one pass: f(t) in f_src -> f(t+2) in f_dst."""
-        check(load().xlbhip_step2(self._h, f_src.handle, f_dst.handle, _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
+        check(load().xlbhip_step2(self._h, _hf(f_src), _hf(f_dst), _h(bc_mask), _h(missing_mask), float(omega), int(timestep)))
 
     def run(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
         """n steps; returns True when the result is in f_b (every pair of steps fused where the kernel exists)."""
         where = C.c_int()
-        check(load().xlbhip_run_any(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
+        check(load().xlbhip_run_any(self._h, _hf(f_a), _hf(f_b), _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
                                     int(n_steps), C.byref(where)))
         return bool(where.value)
 
     def run_timed(self, f_a, f_b, bc_mask, missing_mask, omega, first_timestep, n_steps):
         """As run(); returns (result is in f_b, device milliseconds)."""
         ms, where = C.c_float(), C.c_int()
-        check(load().xlbhip_run_timed(self._h, f_a.handle, f_b.handle, _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
+        check(load().xlbhip_run_timed(self._h, _hf(f_a), _hf(f_b), _h(bc_mask), _h(missing_mask), float(omega), int(first_timestep),
                                       int(n_steps), C.byref(ms), C.byref(where)))
         return bool(where.value), ms.value
 

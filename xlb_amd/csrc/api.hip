@@ -164,10 +164,13 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_clean"] = 1;      // two-step kernel with BCs: work items without boundary cells run the BC-free body (same launch)
   c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
+  c->opts["fuse2_strips"] = 1;     // two-step kernel (D3Q19): halo columns of phase A from the fields' strip buffers (step2_kernel.hpp); 0 = plain pulls
   c->opts["fast_bgk"] = 0;         // two-step kernel: 1 = tolerance-graded fast BGK body (rounding-level differences; +2-4 %)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
   c->opts["halo_telemetry"] = 1;   // slab runs: time the compute stream's wait for the halo event (xlbhip_comm_stats)
+  c->opts["ipc_copy"] = 1;         // ipc transport: 1 = one pull kernel per exchange (8 blocks per plane, no LDS: hidden behind the interior launch),
+                                   // 0 = plane-sized hipMemcpyAsync pulls (copy engines; ~40 us per call on a shared device: profiles/r03/ipc_transport.md)
   c->opts["ipc_timeout_ms"] = 60000;  // ipc transport: bound of every device-side / host-side wait for a neighbour
   c->opts["halo_skip"] = 0;        // 1: MEASUREMENT ONLY — the slab protocol's launches without moving any ghost plane (wrong results)
   c->opts["comm_self_test"] = 0;   // 1: a one-rank RCCL communicator also runs the all-reduce of comm_all_min (tests)
@@ -285,6 +288,7 @@ int xlbhip_field_destroy(xlbhip_field* f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   (void)hipStreamSynchronize(f->ctx->comm_stream);
   comm_forget_buffer(f->ctx, f->base);
+  if (f->strips) (void)hipFree(f->strips);
   (void)hipFree(f->base);
   delete f;
   return 0;
@@ -459,6 +463,7 @@ int xlbhip_stream(xlbhip_ctx* c, int lattice, const xlbhip_field* src, xlbhip_fi
               "stream: field shapes do not match the lattice");
   XLB_REQUIRE(src->dtype != XLBHIP_MISSING && dst->dtype == src->dtype, "stream: dtype mismatch");
   XLB_REQUIRE(src != dst, "stream: f_0 and f_1 must be different fields");
+  touch(dst);
   const size_t n = src->cells();
   return by_lattice(lattice, [&](auto L) {
     hipLaunchKernelGGL(k_stream<decltype(L)>, blocks_for(n), 256, 0, c->stream, view(src), view(dst), dims(src));
@@ -474,6 +479,7 @@ int xlbhip_equilibrium(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_field* 
                   is_float(rho->dtype) && is_float(u->dtype),
               "equilibrium: rho must be (1,...) and u (d,...) float fields on f's grid");
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
+  touch(f);
   const size_t n = f->cells();
   return by_lattice(lattice, [&](auto L) {
     using LL = decltype(L);
@@ -616,6 +622,7 @@ int xlbhip_collide(xlbhip_ctx* c, int lattice, int coll, int cdt, const xlbhip_f
   XLB_REQUIRE(same_grid(f, feq) && same_grid(f, fo), "collide: grids differ");
   XLB_REQUIRE(coll == XLBHIP_BGK || coll == XLBHIP_KBC || coll == XLBHIP_SMAGORINSKY_LES_BGK, "unknown collision %d", coll);
   XLB_REQUIRE(cdt == XLBHIP_F32 || cdt == XLBHIP_F64, "bad compute dtype %d", cdt);
+  touch(fo);
   return by_lattice(lattice, [&](auto L) {
     using LL = decltype(L);
     return cdt == XLBHIP_F32 ? collide_launch<LL, float>(c, coll, f, feq, fo, omega) : collide_launch<LL, double>(c, coll, f, feq, fo, omega);
@@ -635,6 +642,7 @@ int xlbhip_apply_bc_profile(xlbhip_ctx* c, int lattice, int cdt, const xlbhip_bc
   XLB_CHECK_POP(f_post, lattice, "bc(f_post)");
   XLB_REQUIRE(bcm && bcm->dtype == XLBHIP_U8 && bcm->card == 1 && same_grid(bcm, f_post), "bc: bad bc_mask field");
   XLB_REQUIRE(same_grid(f_pre, f_post), "bc: grids differ");
+  touch(f_post);
   XLB_REQUIRE(bc->id >= 1 && bc->id <= 255, "bc id %d out of range", bc->id);
   XLB_REQUIRE(bc->kind >= XLBHIP_BC_EQUILIBRIUM && bc->kind <= XLBHIP_BC_HYBRID_NEQ_REGULARIZED, "unknown bc kind %d (wall-velocity tables live in the stepper)", bc->kind);
   XLB_REQUIRE(bc->kind < XLBHIP_BC_HYBRID_BB_REGULARIZED || (lattice_d(lattice) == 3 && bc->values[4] == 0.0),
@@ -1113,6 +1121,9 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.miss = miss ? static_cast<const uint32_t*>(miss->data) : nullptr;
   p.meta = nullptr;
   p.clean = nullptr;
+  p.strips_src = nullptr;
+  p.strips_dst = nullptr;
+  p.strips = 0;
   p.tile_order = nullptr;
   p.x_segments = 1;
   p.x_cap = 0;
@@ -1238,7 +1249,21 @@ static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
     }
     p.clean = it->second;
   }
-  return launch_step2_d3q19_bgk(p);
+  return p.strips ? launch_step2_d3q19_bgk_strips(p) : launch_step2_d3q19_bgk(p);
+}
+
+// strip buffer of a population field (1 / 32 of it): allocated on first use; false (and no error) when there is no memory for it
+static bool ensure_strips(xlbhip_field* f) {
+  if (f->strips) return true;
+  const size_t bytes = f->planes * f->plane_stride * dtype_size(f->dtype) / 32 + 512;
+  if (hipMalloc(&f->strips, bytes) != hipSuccess) {
+    f->strips = nullptr;
+    (void)hipGetLastError();
+    return false;
+  }
+  f->strips_version = 0;
+  f->strips_oz = -1;
+  return true;
 }
 
 // Pair of steps for a stepper whose Zou-He / Regularized / outflow cells all sit in the planes x = 0 and x = nx - 1
@@ -1320,31 +1345,82 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   }
   p.xcd_swizzle = (int)opt(s->ctx, "fuse2_xcd", 1);
   xlbhip_ctx* c = s->ctx;
+  p.strips = 0;
+  p.strips_src = nullptr;
+  p.strips_dst = nullptr;
+  touch(dst);  // (new contents: whatever was cached on the old ones — its strip buffer — is stale)
   if (s->edge_ext_ok) return step_twice_edge_ext(s, p, src, dst, bcm, miss, omega);
-  if (src->halo == 0 || opt(c, "external_halo", 0)) return launch_step2(s, p);
+  // strip buffers (step2_kernel.hpp): phase A's halo columns come from src's strips, phase B writes dst's.  D3Q19, the
+  // bit-exact body, (8 x 64) tiles; a field whose strips are not those of its current contents gets them rebuilt first.
+  xlbhip_field* srcw = const_cast<xlbhip_field*>(src);
+  const bool native_slab = src->halo > 0 && !opt(c, "external_halo", 0);
+  const bool strips = opt(c, "fuse2_strips", 1) != 0 && s->lattice == XLBHIP_D3Q19 && !p.fast_bgk && p.tile_ty == 8 && p.tile_tz == 64 &&
+                      (src->halo == 0 || native_slab) && src->nx >= 8 && ensure_strips(srcw) && ensure_strips(dst);
+  auto read_strips = [&](StepLaunch& q) -> int {  // q reads src's strips (all interior planes) and writes dst's
+    if (srcw->strips_version != srcw->version || srcw->strips_oz != q.tile_oz) {
+      if (int rc = build_strips(q, src->data, srcw->strips, 0, src->nx)) return rc;
+      srcw->strips_version = srcw->version;
+      srcw->strips_oz = q.tile_oz;
+    }
+    q.strips = 3;
+    q.strips_src = srcw->strips;
+    q.strips_dst = dst->strips;
+    return 0;
+  };
+  auto dst_strips_done = [&]() {  // every interior plane of dst was written by strip-writing launches
+    dst->strips_version = dst->version;
+    dst->strips_oz = p.tile_oz;
+  };
+  if (src->halo == 0 || opt(c, "external_halo", 0)) {
+    if (strips) {
+      if (int rc = read_strips(p)) return rc;
+      if (int rc = launch_step2(s, p)) return rc;
+      dst_strips_done();
+      return 0;
+    }
+    return launch_step2(s, p);
+  }
   // slab protocol for a PAIR of steps: the two ghost planes per side of src are refilled on the comm stream
   // (comm.cpp, depth 2) while the planes whose two-step cone stays inside the slab are updated; the two edge
   // plane pairs follow (each warms its own 3-plane window up from the fresh ghosts).
   const bool overlap = opt(c, "overlap", 1) != 0 && src->nx >= 16;
   XLB_HIP(hipEventRecord(c->ev_edge, c->stream));  // src complete (previous pair)
+  StepLaunch whole = p;
+  if (strips) {  // launches whose phase A pulls from ghost planes (no strips there) only WRITE strips
+    whole.strips = 2;
+    whole.strips_dst = dst->strips;
+  }
+  if (overlap) {
+    // the interior launch goes out BEFORE the exchange is enqueued: posting an exchange costs host time (dozens of copy /
+    // send calls, some of which the runtime may only accept once earlier work of the communication stream has finished —
+    // measured with the ipc transport: 1 ms of exposed wait per pair when the launch came second) and the device must
+    // already have the interior to work on meanwhile
+    p.x_begin = 2;
+    p.x_count = src->nx - 4;
+    p.x_segments = fuse2_segments(s, p);
+    if (strips)
+      if (int rc = read_strips(p)) return rc;
+    if (int rc = launch_step2(s, p)) return rc;
+  }
   XLB_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
-  if (int rc = halo_exchange_on(c, s->lattice, const_cast<xlbhip_field*>(src), c->comm_stream, 2)) return rc;
+  if (int rc = halo_exchange_on(c, s->lattice, srcw, c->comm_stream, 2)) return rc;
   XLB_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
   if (!overlap) {
     XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
-    return launch_step2(s, p);
+    if (int rc = launch_step2(s, whole)) return rc;
+    if (strips) dst_strips_done();
+    return 0;
   }
-  p.x_begin = 2;
-  p.x_count = src->nx - 4;
-  p.x_segments = fuse2_segments(s, p);
-  if (int rc = launch_step2(s, p)) return rc;
   if (int rc = wait_for_halo(c)) return rc;
-  p.x_segments = 1;
-  p.x_count = 2;
-  p.x_begin = 0;
-  if (int rc = launch_step2(s, p)) return rc;
-  p.x_begin = src->nx - 2;
-  return launch_step2(s, p);
+  StepLaunch edge = whole;
+  edge.x_segments = 1;
+  edge.x_count = 2;
+  edge.x_begin = 0;
+  if (int rc = launch_step2(s, edge)) return rc;
+  edge.x_begin = src->nx - 2;
+  if (int rc = launch_step2(s, edge)) return rc;
+  if (strips) dst_strips_done();
+  return 0;
 }
 
 static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss) {
@@ -1528,13 +1604,15 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
   // the planes that do not touch a ghost are updated; the two edge planes follow.
   const bool overlap = opt(c, "overlap", 1) != 0 && src->nx > 2;
   XLB_HIP(hipEventRecord(c->ev_edge, c->stream));  // src complete (previous step)
+  if (overlap) {  // interior first, then the exchange is posted (see step_twice)
+    p.x_begin = 1;
+    p.x_count = src->nx - 2;
+    if (int rc = launch_any(s, p)) return rc;
+  }
   XLB_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
   if (int rc = halo_exchange_on(c, s->lattice, const_cast<xlbhip_field*>(src), c->comm_stream)) return rc;
   XLB_HIP(hipEventRecord(c->ev_halo, c->comm_stream));
   if (overlap) {
-    p.x_begin = 1;
-    p.x_count = src->nx - 2;
-    if (int rc = launch_any(s, p)) return rc;
     if (int rc = wait_for_halo(c)) return rc;
     p.x_begin = 0;
     p.x_count = 1;
@@ -1551,6 +1629,7 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
 // one step src -> dst; ExtrapolationOutflowBC cells get their auxiliary data afterwards (nse_stepper.py:270-272)
 static int step_once(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* dst, const xlbhip_field* bcm, const xlbhip_field* miss,
                      double omega) {
+  touch(dst);  // (its strip buffer, if any, no longer matches)
   if (int rc = step_kernels(s, src, dst, bcm, miss, omega)) return rc;
   return outflow_aux(s, src, dst, bcm, miss);
 }

@@ -186,6 +186,23 @@ __global__ void k_ipc_wait(const uint32_t* a, const uint32_t* b, uint32_t seq, u
   __threadfence_system();
 }
 
+// Alternative to the copy calls (option "ipc_copy" = 1): ONE launch pulls every plane of an exchange through the IPC mappings,
+// 16 bytes per lane; blockIdx.y = message.  Few blocks: it runs beside the interior launch on wave slots that kernel leaves free.
+struct IpcPullTable {
+  static const int MAX = 56;  // D3Q27, depth 2: 2 x (27 + 9) messages would not fit: the caller splits
+  const void* src[MAX];
+  void* dst[MAX];
+};
+
+__global__ void __launch_bounds__(256) k_ipc_pull(IpcPullTable tab, size_t bytes) {
+  const char* s = static_cast<const char*>(tab.src[blockIdx.y]);
+  char* d = static_cast<char*>(tab.dst[blockIdx.y]);
+  const size_t n16 = bytes / 16, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+    reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  for (size_t i = n16 * 16 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < bytes; i += stride) d[i] = s[i];
+}
+
 static double now_s() {
   timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -301,6 +318,26 @@ static int run_messages(xlbhip_ctx* c, const BufLayout& local, void* alloc_base,
                        has_right ? cm->dev(&cm->rank_block(rr)->flags.ready) : nullptr, seq, ticks, cm->dev(&cm->rank_block(r)->flags.error));
     XLB_HIP(hipGetLastError());
     // 3. pull: what the left neighbour would have sent right lands in my left ghosts, and vice versa
+    if (opt(c, "ipc_copy", 0) == 1 && (reinterpret_cast<uintptr_t>(local.data) % 16 == 0) && bytes % 16 == 0) {
+      IpcPullTable tab;
+      int n_tab = 0;
+      auto flush = [&]() {
+        if (n_tab == 0) return 0;
+        hipLaunchKernelGGL(k_ipc_pull, dim3(8, n_tab), 256, 0, st, tab, bytes);
+        XLB_HIP(hipGetLastError());
+        n_tab = 0;
+        return 0;
+      };
+      for (const HaloMsg& m : msgs) {
+        const bool from_left = m.dir > 0 && has_left, from_right = m.dir < 0 && has_right;
+        if (!from_left && !from_right) continue;
+        tab.src[n_tab] = from_left ? left_buf.send_ptr(m) : right_buf.send_ptr(m);
+        tab.dst[n_tab] = local.recv_ptr(m);
+        if (++n_tab == IpcPullTable::MAX)
+          if (int rc = flush()) return rc;
+      }
+      return flush();
+    }
     for (const HaloMsg& m : msgs) {
       if (m.dir > 0 && has_left) XLB_HIP(hipMemcpyAsync(local.recv_ptr(m), left_buf.send_ptr(m), bytes, hipMemcpyDefault, st));
       if (m.dir < 0 && has_right) XLB_HIP(hipMemcpyAsync(local.recv_ptr(m), right_buf.send_ptr(m), bytes, hipMemcpyDefault, st));

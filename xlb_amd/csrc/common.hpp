@@ -80,6 +80,11 @@ struct xlbhip_field {
   void* base = nullptr;  // hipMalloc pointer
   void* data = nullptr;  // base + guard
   uint64_t version = 0;  // bumped by every C-ABI call that writes the field (caches keyed on a mask's contents)
+  // strip buffer of a population field (two-step kernel, step2_kernel.hpp "Strip buffers"): 1 / 32 of the field, allocated on first
+  // use; valid for the contents `strips_version` and the z origin `strips_oz` of the tiling only
+  void* strips = nullptr;
+  uint64_t strips_version = 0;
+  int strips_oz = -1;
   size_t cells() const { return (size_t)nx * ny * nz; }
   size_t cells_with_halo() const { return (size_t)(nx + 2 * halo) * ny * nz; }
 };

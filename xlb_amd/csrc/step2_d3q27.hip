@@ -9,6 +9,6 @@ int launch_step2_d3q27_bgk(const StepLaunch& p) { return launch2<D3Q27, 0, 8, 64
 int launch_step2_d3q27_kbc(const StepLaunch& p) {
   if (p.compute_dtype == XLBHIP_F32) return launch2f<D3Q27, 0, 8, 48, false, true, false, float, XLBHIP_KBC>(p);
   XLB_REQUIRE(p.fast_math, "two-step kernel: the bit-exact fp64 KBC collision is not built (step2_eligible)");
-  return launch2f<D3Q27, 0, 8, 48, false, true, false, double, XLBHIP_KBC | COLL_FAST>(p);
+  return launch2f<D3Q27, 0, 8, 48, false, true, false, double, XLBHIP_KBC | COLL_FAST | (XLB_KBC_GAMMA32 ? COLL_G32 : 0)>(p);  // (fp32 store: gamma reduction in fp32)
 }
 }  // namespace xlb

@@ -205,12 +205,16 @@ __device__ __forceinline__ void step2_seg_range(int x_begin, int x_count, int n_
 
 // The body of the kernel for one block; the LDS arrays belong to the __global__ wrapper below (so that the wrapper can
 // run either boundary-condition form of the body in the same allocation).
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST, bool SLACK = false>
-__device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsigned* ldsmeta, T* bcval) {
+// STRIPS (D3Q19 / (TY x 64) tiles): bit 0 = phase A reads the halo columns of its grown tile from the source field's STRIP buffer,
+// bit 1 = phase B also writes the destination field's strips.  See "Strip buffers" below.
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, int GMAX, bool PIN, bool FAST, bool SLACK = false, int STRIPS = 0>
+__device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsigned* ldsmeta, T* bcval, S* strip_stage = nullptr) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED, SLACK>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
+  constexpr bool SR = (STRIPS & 1) != 0, SW = (STRIPS & 2) != 0;
+  static_assert(STRIPS == 0 || (TZ == 64 && sizeof(S) == 4), "strip buffers: (TY x 64) tiles, 4-byte store type");
   // f(t+1) lives in LDS in the STORE type: the single-step kernel rounds it to that type on its way through memory, so the
   // ring holds exactly what two single steps would have stored, whatever the compute type (fp64 KBC: FP64FP32)
   static_assert(sizeof(S) == 4, "k_step2 keeps f(t+1) as 4-byte store values in LDS");
@@ -269,7 +273,11 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   const int ta = act_a ? t : NE - 1;
   // row-aligned lanes ((TY x 64) tiles): wave j < EY pulls the 64 interior cells of grown row j (for c_z = 0 one aligned 256-byte
   // piece per pull instead of the tail of one row + the head of the next), the last wave the two halo columns of all rows
-  constexpr bool ROWMAP = XLB_STEP2_ROWMAP != 0 && TZ == 64;
+  constexpr bool ROWMAP = (XLB_STEP2_ROWMAP != 0 || SR) && TZ == 64;
+  // strip buffers: the last wave holds the 2 x EY halo-column cells of the grown tile (ROWMAP) and pulls for them from the
+  // strips — the same instructions as every other wave, with the strip buffer's geometry in place of the field's
+  const bool halo_wave = SR && __builtin_amdgcn_readfirstlane(t) >= G::EY * 64;
+  const unsigned tile_zc = tile % tiles_z;  // tile column: boundary tile_zc is its left edge, tile_zc + 1 (periodic) its right edge
   const int ja = !ROWMAP ? ta / EZ : (ta < G::EY * 64 ? ta / 64 : (ta - G::EY * 64) / 2);
   const int ka = !ROWMAP ? ta % EZ : (ta < G::EY * 64 ? 1 + ta % 64 : ((ta & 1) ? EZ - 1 : 0));
   const int slot_a = ja * EZ + ka;  // my cell inside a grown-tile slot
@@ -283,6 +291,44 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   Zb[0] = (unsigned)((za + 1 == nz) ? 0 : za + 1) * ES;
   Zb[1] = (unsigned)za * ES;
   Zb[2] = (unsigned)((za == 0) ? nz - 1 : za - 1) * ES;
+  if constexpr (SR) {
+    if (halo_wave) {
+      // S_l[x][b][y][j] = f_l(x, y, z_b - 1 - c_z(l) + j): what the halo cell at z_b - 1 (j = 0: left halo column of the tile
+      // whose left edge is boundary b) or at z_b (j = 1: right halo column of the tile whose right edge it is) pulls, whatever c_z
+      const unsigned b = ka == 0 ? tile_zc : (tile_zc + 1 == tiles_z ? 0u : tile_zc + 1);
+      const unsigned zoff = (b * (unsigned)ny * 2u + (ka == 0 ? 0u : 1u)) * ES;
+      Yb[0] = (unsigned)((ya + 1 == ny) ? 0 : ya + 1) * 2u * ES;
+      Yb[1] = (unsigned)ya * 2u * ES;
+      Yb[2] = (unsigned)((ya == 0) ? ny - 1 : ya - 1) * 2u * ES;
+      Zb[0] = Zb[1] = Zb[2] = zoff;
+    }
+  }
+#if defined(XLB_STEP2_WHATIF) && XLB_STEP2_WHATIF != 0
+  // MEASUREMENT ONLY (wrong results; never in the shipped build — tools/r03_whatif.sh): what would phase A's pulls cost if the
+  // halo columns (bit 0) / halo rows (bit 1) of the grown tile came for free?  Sources outside the tile proper are clamped onto
+  // its edge cells, so a block touches no sector that belongs to a neighbouring tile: the upper bound of what compact strip
+  // buffers (bit 0) or perfect L2 sharing between neighbouring tiles (bits 0 + 1) could save.
+  {
+    auto zsrc = [&](int cz) {
+      int kk = ka - cz;  // grown z index of the source: -1 .. TZ + 2; the tile proper is 1 .. TZ
+      if (XLB_STEP2_WHATIF & 1) kk = kk < 1 ? 1 : (kk > TZ ? TZ : kk);
+      int z = tz0 - 1 + kk;
+      z = z < 0 ? z + nz : (z >= nz ? z - nz : z);
+      return (unsigned)z * ES;
+    };
+    auto ysrc = [&](int cy) {
+      int jj = ja - cy;
+      if (XLB_STEP2_WHATIF & 2) jj = jj < 1 ? 1 : (jj > TY ? TY : jj);
+      int y = ty0 - 1 + jj;
+      y = y < 0 ? y + ny : (y >= ny ? y - ny : y);
+      return (unsigned)y * (unsigned)nz * ES;
+    };
+    for (int c = -1; c <= 1; ++c) {
+      Zb[c + 1] = zsrc(c);
+      Yb[c + 1] = ysrc(c);
+    }
+  }
+#endif
   const unsigned cell_a = (unsigned)ya * (unsigned)nz + (unsigned)za;
 
   // ---- phase-B cell of this thread (tile proper); waves beyond the tile shadow a valid cell ----
@@ -360,7 +406,14 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     static_for<Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-      const S* row = a.src + (size_t)l * a.plane_stride + (ptrdiff_t)Xs[cx + 1] * pc;  // uniform
+      const S* row;  // uniform
+      if constexpr (SR) {
+        // (the strip buffer mirrors the field's population / plane structure at 1 / 32 of its size: 2 values per 64 cells of a row)
+        const ptrdiff_t off = (ptrdiff_t)((size_t)l * a.plane_stride) + (ptrdiff_t)Xs[cx + 1] * pc;
+        row = halo_wave ? a.strips_src + (off >> 5) : a.src + off;
+      } else {
+        row = a.src + (size_t)l * a.plane_stride + (ptrdiff_t)Xs[cx + 1] * pc;
+      }
       raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
     });
     if constexpr (HASBC != 0) {
@@ -578,6 +631,53 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         st_aligned<S, 1, true>(drow, cell_b * ES, v);
       });
     }
+    if constexpr (SW) {
+      // the two outermost cells of the row on either side feed the strips: 16 values per population and plane
+      // ([row][e]: c_z = -1 -> columns 0, 1 (left edge); c_z = +1 -> columns TZ - 2, TZ - 1 (right edge); c_z = 0 -> column 0
+      // (left edge) and column TZ - 1 (right edge)), staged in LDS and written out by the waves without output cells
+      if (kb < 2 || kb >= TZ - 2) {
+        S* stg = strip_stage + (d & 1) * (Q * 16) + jb * 2;
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int cz = L::c(2, l);
+          const S v = to_store<S, T>(f[l]);
+          if constexpr (cz == -1) {
+            if (kb < 2) stg[l * 16 + kb] = v;
+          } else if constexpr (cz == 1) {
+            if (kb >= TZ - 2) stg[l * 16 + kb - (TZ - 2)] = v;
+          } else {
+            if (kb == 0) stg[l * 16] = v;
+            if (kb == TZ - 1) stg[l * 16 + 1] = v;
+          }
+        });
+      }
+    }
+  };
+  // strips of plane x (staged by phase B of ring plane d, visible since the barrier that ended that iteration): the 192
+  // lanes without output cells write 16 values of 12 populations per pass
+  auto flush_strips = [&](int x, int d) __attribute__((always_inline)) {
+    if constexpr (SW) {
+      if (act_b) return;
+      constexpr unsigned CZP = [] { unsigned m = 0; for (int l = 0; l < Q; ++l) m |= (L::c(2, l) == 1 ? 1u : 0u) << l; return m; }();
+      constexpr unsigned CZM = [] { unsigned m = 0; for (int l = 0; l < Q; ++l) m |= (L::c(2, l) == -1 ? 1u : 0u) << l; return m; }();
+      const int tl = t - G::NB, g = tl >> 4, i = tl & 15, r = i >> 1, e = i & 1;
+      int yy = ty0 + r;
+      yy = yy >= ny ? yy - ny : yy;
+      const unsigned bL = tile_zc, bR = tile_zc + 1 == tiles_z ? 0u : tile_zc + 1;
+      constexpr int GROUPS = (G::THREADS - G::NB) / 16;
+      static_assert(GROUPS >= 1, "no idle lanes to write the strips");
+#pragma unroll
+      for (int rr = 0; rr * GROUPS < Q; ++rr) {
+        const int l = rr * GROUPS + g;
+        if (l < Q) {
+          const int cz = (int)((CZP >> l) & 1u) - (int)((CZM >> l) & 1u);
+          const unsigned b = cz < 0 ? bL : (cz > 0 ? bR : (e == 0 ? bL : bR));
+          const unsigned j = cz != 0 ? (unsigned)e : (e == 0 ? 1u : 0u);
+          const S v = strip_stage[(d & 1) * (Q * 16) + l * 16 + i];
+          a.strips_dst[(((ptrdiff_t)((size_t)l * a.plane_stride) + (ptrdiff_t)x * pc) >> 5) + (ptrdiff_t)(((size_t)b * (unsigned)ny + (unsigned)yy) * 2u + j)] = v;
+        }
+      }
+    }
   };
 
   // Plane x_lo + p is plane q = p + 1 of the ring (p = -1: the periodic image / ghost plane below the segment).
@@ -604,6 +704,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     unsigned wa = 0;
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
     XLB_TRACE(d, 0);
+    if (d > 0) flush_strips(x - 1, d - 1);
     phase_b(x, d);
     XLB_TRACE(d, 2);
     if constexpr (!SLACK) lds_barrier();  // every reader of the buffers about to be overwritten is done (the slack ring has a spare buffer instead)
@@ -623,6 +724,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     lds_barrier();  // plane x + 2 visible
     XLB_TRACE(d, 7);
   }
+  if (x_hi > x_lo) flush_strips(x_hi - 1, x_hi - 1 - x_lo);
 }
 
 // Work items (tile column x x-segment) WITHOUT a single boundary cell in their grown tile and plane range run the body
@@ -630,19 +732,54 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
 // `a.clean[blockIdx.x]` (k_step2_clean, rebuilt with the meta words every run) is block-uniform.  On the 512^3 cavity that
 // is every segment of an interior tile column but its first and last one, 54 % of the items.  (Round 1 tried the same
 // split as separate launches on two streams and lost to launch tails / kernel mixing; one launch has neither.)
-template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST>
+template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, int STRIPS = 0>
 __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), (S2Geom<L, HASBC, TY, TZ, PACKED>::WAVES_PER_SIMD)) k_step2(const StepArgs<T, S> a) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   __shared__ S lds[G::RING_PLANES * G::NE + G::STAGE_ELEMS];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
   __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
+  __shared__ S strip_stage[(STRIPS & 2) ? 2 * L::Q * 16 : 1];   // [ring plane & 1][population][row][e]: the plane's strip values on their way out
+  static_assert(G::LDS_BYTES + ((STRIPS & 2) ? 2 * L::Q * 16 * 4 : 0) <= 160 * 1024, "strip staging does not fit the LDS");
   if constexpr (HASBC != 0) {
     if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
-      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST, G::SLACK>(a, lds, ldsmeta, bcval);
+      step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST, G::SLACK, STRIPS>(a, lds, ldsmeta, bcval, strip_stage);
       return;
     }
   }
-  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false), FAST, (HASBC == 0 && G::SLACK && XLB_STEP2_SLACK_PLAIN != 0)>(a, lds, ldsmeta, bcval);
+  step2_body<L, T, S, COLL, HASBC, TY, TZ, SLAB, PACKED, (HASBC != 0 ? 3 : XLB_STEP2_PLAIN_GMAX), (HASBC != 0 ? XLB_PIN_BC : false), FAST, (HASBC == 0 && G::SLACK && XLB_STEP2_SLACK_PLAIN != 0), STRIPS>(a, lds, ldsmeta, bcval, strip_stage);
+}
+
+// Strip buffers (round 3).  The grown tile's two halo COLUMNS cost phase A 64-byte sectors for 4-byte values — 5-6 sectors per
+// 66-cell row for 4 of payload, in lines that belong to the neighbouring tile (another block, often another XCD's L2): reads
+// 1.57x the field on the 512^3 cavity, and a what-if build that gets those columns for free runs 10 % faster
+// (profiles/r03/step2_strips.md).  So every population field carries a STRIP buffer, 1 / 32 of its size, same population /
+// plane structure:  S_l[x][b][y][j] = f_l(x, y, z_b - 1 - c_z(l) + j),  b = tile boundary (z_b = 64 b + tile_oz), j = 0, 1 —
+// for every population exactly the two values the halo cells left and right of boundary b pull from row (x, y).  Phase B
+// writes them with the field (two cells per row edge, staged through LDS, written by the waves without output cells: +3 %
+// bytes); phase A's last wave — the 2 x EY halo cells — pulls from it: per population and plane 4 sectors instead of ~15.
+// Anything else that writes the field invalidates its strips (api.hip: strips_version); k_build_strips rebuilds them.
+template <class S>
+__global__ void k_build_strips(const S* __restrict__ f, S* __restrict__ strips, size_t plane_stride, int q, int x_begin, int x_count, int ny, int nz,
+                               int tile_oz, unsigned czp, unsigned czm) {
+  // one thread per (population, plane, boundary, row): both values; f / strips point at interior plane 0
+  const int nb = nz / 64;
+  const size_t n = (size_t)q * x_count * nb * ny;
+  const size_t pc = (size_t)ny * nz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i % ny);
+    const int b = (int)((i / ny) % nb);
+    const int x = x_begin + (int)((i / ((size_t)ny * nb)) % x_count);
+    const int l = (int)(i / ((size_t)ny * nb * x_count));
+    const int cz = (int)((czp >> l) & 1u) - (int)((czm >> l) & 1u);
+    const ptrdiff_t off = (ptrdiff_t)((size_t)l * plane_stride) + (ptrdiff_t)x * (ptrdiff_t)pc;
+    const S* row = f + off + (size_t)y * nz;
+    S* out = strips + (off >> 5) + ((size_t)b * ny + y) * 2;
+    int z0 = b * 64 + tile_oz - 1 - cz;
+    z0 = z0 < 0 ? z0 + nz : (z0 >= nz ? z0 - nz : z0);
+    const int z1 = z0 + 1 == nz ? 0 : z0 + 1;
+    out[0] = row[z0];
+    out[1] = row[z1];
+  }
 }
 
 // clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel

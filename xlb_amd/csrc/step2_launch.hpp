@@ -17,7 +17,7 @@ inline int step2_eff_cap(const StepLaunch& p) {
 }
 inline int step2_eff_swizzle(const StepLaunch& p, unsigned tiles) { return (p.xcd_swizzle && tiles % 8u == 0u) ? 1 : 0; }
 
-template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T = float, int COLL = XLBHIP_BGK>
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T = float, int COLL = XLBHIP_BGK, int STRIPS = 0>
 static int launch2f(const StepLaunch& p);
 
 // fast_bgk = 1 (opt-in): the tolerance-graded fast BGK body (cell.hpp: bgk_fast).  Measured: 20 % fewer VALU instructions buy
@@ -29,7 +29,7 @@ static int launch2(const StepLaunch& p) {
 }
 
 // T / COLL: compute type and collision (cell.hpp collide<>) of the instantiation; the store type is always fp32
-template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T, int COLL>
+template <class L, int HASBC, int TY, int TZ, bool SLAB, bool PACKED, bool FAST, class T, int COLL, int STRIPS>
 static int launch2f(const StepLaunch& p) {
   static_assert(HASBC == 0 || (sizeof(T) == 4 && COLL == XLBHIP_BGK), "boundary-condition tables of the two-step kernel are fp32 / BGK");
   StepArgs<T, float> a;
@@ -42,6 +42,13 @@ static int launch2f(const StepLaunch& p) {
   a.meta = p.meta ? p.meta + ghost : nullptr;
   a.tile_order = p.tile_order;
   a.clean = (HASBC != 0) ? p.clean : nullptr;
+  // (the strip buffer mirrors the field at 1 / 32: its interior plane 0 sits ghost / 32 elements in)
+  a.strips_src = (STRIPS & 1) ? static_cast<const float*>(p.strips_src) + (ghost >> 5) : nullptr;
+  a.strips_dst = (STRIPS & 2) ? static_cast<float*>(p.strips_dst) + (ghost >> 5) : nullptr;
+  if constexpr (STRIPS != 0) {
+    XLB_REQUIRE(((STRIPS & 1) == 0 || p.strips_src) && ((STRIPS & 2) == 0 || p.strips_dst), "two-step kernel: strip buffers missing");
+    XLB_REQUIRE(p.plane_stride % 32 == 0 && ((size_t)p.ny * p.nz) % 32 == 0, "two-step kernel: strip buffers need 32-element aligned planes");
+  }
   a.x_segments = step2_eff_segments(p);
   a.x_cap = step2_eff_cap(p);
   a.tile_oy = p.tile_oy;
@@ -70,7 +77,7 @@ static int launch2f(const StepLaunch& p) {
   a.extra.smag_cs = p.smag_cs;
   const unsigned tiles = (unsigned)(p.ny / TY) * (unsigned)(p.nz / TZ);
   a.xcd_swizzle = step2_eff_swizzle(p, tiles);
-  hipLaunchKernelGGL((k_step2<L, T, float, COLL, HASBC, TY, TZ, SLAB, PACKED, FAST>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
+  hipLaunchKernelGGL((k_step2<L, T, float, COLL, HASBC, TY, TZ, SLAB, PACKED, FAST, STRIPS>), dim3(tiles * (unsigned)a.x_segments), dim3(S2Geom<L, HASBC, TY, TZ, PACKED>::THREADS), 0, p.stream, a);
   XLB_HIP(hipGetLastError());
   return 0;
 }

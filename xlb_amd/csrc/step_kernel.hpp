@@ -42,6 +42,8 @@ struct StepArgs {
   int tile_oy, tile_oz;        // two-step kernel only: origin shift of the tiling (periodic), see step2_kernel.hpp
   const uint32_t* meta;   // two-step kernel only: id | missing << 8 per cell (built per run), else nullptr
   const uint8_t* clean;   // two-step kernel only: per block, 1 = no boundary cell in its work item (k_step2_clean), or nullptr
+  const S* strips_src;    // two-step kernel with strip buffers (step2_kernel.hpp): the source field's strips / the destination's,
+  S* strips_dst;          //   advanced to interior plane 0 like src / dst; else nullptr
   const T* bc_values;     // [256][27]: feq of equilibrium BCs / moving-wall terms
   const uint8_t* bc_kind; // [256] K_*; used only when n_bc > MAX_FAST_BCS
   // per-cell prescribed values of Zou-He / Regularized BCs built with a profile (extended variant only): sorted

@@ -14,6 +14,9 @@ struct StepLaunch {
   const uint32_t* meta;  // two-step kernel only
   const uint32_t* tile_order;  // two-step kernel only
   const uint8_t* clean;        // two-step kernel only: per-block "no boundary cells" flags for THIS launch geometry, or nullptr
+  const void* strips_src;      // two-step kernel only: strip buffers of the source / destination field (storage plane 0), or nullptr
+  void* strips_dst;
+  int strips;                  // two-step kernel only: 0 = none, 3 = phase A reads + phase B writes them, 2 = phase B writes them only
   int x_segments;              // two-step kernel only
   int x_cap;                   // two-step kernel only: thin first / last segment (planes), 0 = uniform cuts
   int tile_oy, tile_oz;        // two-step kernel only: periodic origin shift of the tiling (0 .. tile - 1)
@@ -180,9 +183,11 @@ int launch_step_ext(const StepLaunch& p) {
 template <class L, int COLL>
 int launch_step_f64(const StepLaunch& p) {
   const int c = p.compute_dtype, s = p.store_dtype;
+  // (a store type narrower than the compute type: the gamma reduction of the fast KBC collision runs in fp32, cell.hpp COLL_G32)
+  constexpr int NARROW = COLL | (XLB_KBC_GAMMA32 ? COLL_G32 : 0);
   if (c == XLBHIP_F64 && s == XLBHIP_F64) return launch_policy<L, double, double, COLL>(p);
-  if (c == XLBHIP_F64 && s == XLBHIP_F32) return launch_policy<L, double, float, COLL>(p);
-  if (c == XLBHIP_F64 && s == XLBHIP_F16) return launch_policy<L, double, _Float16, COLL>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F32) return launch_policy<L, double, float, NARROW>(p);
+  if (c == XLBHIP_F64 && s == XLBHIP_F16) return launch_policy<L, double, _Float16, NARROW>(p);
   XLB_FAIL("fast fp64 variant asked for compute=%d store=%d", c, s);
 }
 
@@ -191,6 +196,8 @@ int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 // two steps per pass (step2_kernel.hpp): f(t) in src -> f(t+2) in dst
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
+int launch_step2_d3q19_bgk_strips(const StepLaunch& p);  // p.strips != 0 (step2_d3q19_strips.hip)
+int build_strips(const StepLaunch& p, const void* field, void* strips, int x_begin, int x_count);
 int launch_step2_d3q27_bgk(const StepLaunch& p);
 int launch_step2_d3q27_kbc(const StepLaunch& p);
 int step2_build_clean(const StepLaunch& p, uint8_t* out);
