@@ -35,7 +35,17 @@ oracle: oracle/liblbmref.so
 oracle/liblbmref.so: oracle/lbm_ref.c oracle/lbm_ref_body.inc
 	gcc -O2 -fPIC -shared -fopenmp -ffp-contract=off -fno-fast-math -o $@ $< -lm
 
+# Host-side AddressSanitizer / UBSan build (tools/asan_host.py): only the two translation units with host logic are
+# instrumented, for the host compilation only; the kernel objects are the ordinary ones.  ~12 minutes (api.hip's device pass).
+ASANDIR := build/asan
+ASANFLAGS := --offload-arch=$(ARCH) -O1 -g -std=c++17 -ffp-contract=off -fPIC -Iinclude -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer
+asan: $(LIB)
+	@mkdir -p $(ASANDIR)
+	$(HIPCC) $(ASANFLAGS) -c $(CSRC)/api.hip -o $(ASANDIR)/api.o
+	$(HIPCC) $(ASANFLAGS) -x hip -c $(CSRC)/comm.cpp -o $(ASANDIR)/comm.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -fsanitize=address,undefined -o $(ASANDIR)/libxlbhip_asan.so $(ASANDIR)/api.o $(ASANDIR)/comm.o $(filter-out $(OBJDIR)/api.o $(OBJDIR)/comm.o,$(OBJS)) -ldl
+
 clean:
 	rm -rf build xlb_amd/lib/libxlbhip.so oracle/liblbmref.so
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan

@@ -1465,7 +1465,11 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // D3Q27 KBC pairs on request only (fuse2 = 2): ~1100 (fp32) / 810 (fast fp64) VALU instructions per cell and 8 waves per CU make
     // the two-step form issue-bound — 384^3: 2.41 (FP64FP32) / 2.52 (FP32FP32) ms per step against 2.21 / 2.16 of the HBM-bound
     // single-step kernel (profiles/r02/d3q27_kbc_two_step.txt)
-    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) return false;
+    // Round 3: with the gamma reduction in fp32 (cell.hpp COLL_G32: fp64 compute, fp32 store — BASELINE configs[4]) the pairs WIN,
+    // 2.18 against 2.24 ms per step at 384^3 (profiles/r03/kbc_gamma32.md); fp32 KBC pairs still lose and stay on request.
+    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC &&
+        !(XLB_KBC_GAMMA32 && p.compute_dtype == XLBHIP_F64 && p.store_dtype == XLBHIP_F32 && p.fast_math))
+      return false;
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
     const long items = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz) * fuse2_segments(s, p), cus = fill_cus(s->ctx);

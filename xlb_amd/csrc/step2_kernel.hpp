@@ -213,7 +213,13 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   using R = S2Ring<L, HASBC, PACKED, SLACK>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
+#if defined(XLB_STRIPS_NOREAD)  // measurement builds (tools/r03_call4.sh): one half of the mechanism at a time
+  constexpr bool SR = false, SW = (STRIPS & 2) != 0;
+#elif defined(XLB_STRIPS_NOWRITE)
+  constexpr bool SR = (STRIPS & 1) != 0, SW = false;
+#else
   constexpr bool SR = (STRIPS & 1) != 0, SW = (STRIPS & 2) != 0;
+#endif
   static_assert(STRIPS == 0 || (TZ == 64 && sizeof(S) == 4), "strip buffers: (TY x 64) tiles, 4-byte store type");
   // f(t+1) lives in LDS in the STORE type: the single-step kernel rounds it to that type on its way through memory, so the
   // ring holds exactly what two single steps would have stored, whatever the compute type (fp64 KBC: FP64FP32)
