@@ -38,6 +38,12 @@
 #ifndef XLB_STEP2_ROWMAP
 #define XLB_STEP2_ROWMAP 0
 #endif
+#ifndef XLB_STEP2_ROWMAP_PLAIN
+#define XLB_STEP2_ROWMAP_PLAIN 1
+#endif
+#ifndef XLB_STEP2_ROWMAP_CLEAN
+#define XLB_STEP2_ROWMAP_CLEAN 0  // the BC-free body of the clean work items inside a BC kernel (slack ring): measurement builds
+#endif
 #ifndef XLB_STEP2_STAGE
 #define XLB_STEP2_STAGE 0
 #endif
@@ -279,7 +285,10 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   const int ta = act_a ? t : NE - 1;
   // row-aligned lanes ((TY x 64) tiles): wave j < EY pulls the 64 interior cells of grown row j (for c_z = 0 one aligned 256-byte
   // piece per pull instead of the tail of one row + the head of the next), the last wave the two halo columns of all rows
-  constexpr bool ROWMAP = (XLB_STEP2_ROWMAP != 0 || SR) && TZ == 64;
+  // Row-aligned lanes are the default of the stand-alone BC-free kernel (two barriers per plane): periodic 512^3 2.28 -> 2.11-2.16
+  // ms/step in round 3's A/B (round 2 measured -2...3 %); the bodies of the BC kernel lose 0-3 % with it and keep the dense mapping.
+  constexpr bool ROWMAP = (XLB_STEP2_ROWMAP != 0 || SR || (XLB_STEP2_ROWMAP_PLAIN != 0 && HASBC == 0 && !SLACK) ||
+                           (XLB_STEP2_ROWMAP_CLEAN != 0 && HASBC == 0 && SLACK)) && TZ == 64;
   // strip buffers: the last wave holds the 2 x EY halo-column cells of the grown tile (ROWMAP) and pulls for them from the
   // strips — the same instructions as every other wave, with the strip buffer's geometry in place of the field's
   const bool halo_wave = SR && __builtin_amdgcn_readfirstlane(t) >= G::EY * 64;
@@ -710,7 +719,6 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     unsigned wa = 0;
     if constexpr (HASBC != 0) wa = meta_load(wrapx(x + 3), cell_a);  // used after phase B: a whole phase of latency cover
     XLB_TRACE(d, 0);
-    if (d > 0) flush_strips(x - 1, d - 1);
     phase_b(x, d);
     XLB_TRACE(d, 2);
     if constexpr (!SLACK) lds_barrier();  // every reader of the buffers about to be overwritten is done (the slack ring has a spare buffer instead)
@@ -726,6 +734,11 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     // put the fp64 body into scratch)
     if constexpr ((COLL & 3) != XLBHIP_BGK) __builtin_amdgcn_sched_barrier(0);
     issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
+    // the strips of plane x - 1 leave here, BEHIND the pulls just issued: the waves that write them (the last ones of the block, the
+    // plane's critical path) next wait for vector memory a whole iteration later, when these stores have long been acknowledged.
+    // (At the top of the iteration the stores were younger than the pulls finish_a waits for: their acknowledgement latency landed
+    // on every plane — periodic 512^3 2.28 -> 2.81 ms/step, profiles/r03/step2_strips.md.)
+    if (d > 0) flush_strips(x - 1, d - 1);
     XLB_TRACE(d, 6);
     lds_barrier();  // plane x + 2 visible
     XLB_TRACE(d, 7);
