@@ -78,6 +78,20 @@ __device__ __forceinline__ void trace_stamp(int d, int e) {
 #define XLB_TRACE(d, e)
 #endif
 
+// populations by c_z class (strip buffers)
+template <class L>
+constexpr int n_cz0() {
+  int n = 0;
+  for (int l = 0; l < L::Q; ++l) n += L::c(2, l) == 0 ? 1 : 0;
+  return n;
+}
+template <class L>
+constexpr int nth_cz(int cz, int k) {  // k-th population (index order) with c_z == cz
+  for (int l = 0; l < L::Q; ++l)
+    if (L::c(2, l) == cz && k-- == 0) return l;
+  return 0;
+}
+
 // LDS ring of f(t+1), packed by population LIFETIME.  Plane p of f(t+1) is produced by phase A of iteration p - 2 and
 // consumed by phase B of plane p + c_x (the pull f_l(x) <- f_l(x - c_x)): its c_x = -1 populations one iteration later,
 // the c_x = 0 ones two, the c_x = +1 ones three iterations later.  So population l needs life(l) = 1 / 2 / 3 plane
@@ -380,6 +394,17 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     }
   };
   const ptrdiff_t pc = (ptrdiff_t)plane_cells;
+  // where phase A pulls from
+  const S* pull_base = a.src;
+  size_t pull_stride = a.plane_stride;
+  ptrdiff_t pull_pc = pc;
+  if constexpr (SR) {
+    if (halo_wave) {
+      pull_base = a.strips_src;
+      pull_stride = a.plane_stride >> 5;
+      pull_pc = pc >> 5;
+    }
+  }
   auto meta_load = [&](int plane, unsigned cell) __attribute__((always_inline)) -> unsigned { return (a.meta + (ptrdiff_t)plane * pc)[cell]; };
 
   auto finish = [&](T(&f)[Q], bool fullway) __attribute__((always_inline)) {
@@ -421,14 +446,9 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     static_for<Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
-      const S* row;  // uniform
-      if constexpr (SR) {
-        // (the strip buffer mirrors the field's population / plane structure at 1 / 32 of its size: 2 values per 64 cells of a row)
-        const ptrdiff_t off = (ptrdiff_t)((size_t)l * a.plane_stride) + (ptrdiff_t)Xs[cx + 1] * pc;
-        row = halo_wave ? a.strips_src + (off >> 5) : a.src + off;
-      } else {
-        row = a.src + (size_t)l * a.plane_stride + (ptrdiff_t)Xs[cx + 1] * pc;
-      }
+      // uniform; for the halo wave of a strip-buffer build `pull_base` is the strip buffer, which mirrors the field's population /
+      // plane structure at 1 / 32 of its size (pull_stride, pull_pc: chosen once per wave, so the per-population arithmetic is the same)
+      const S* row = pull_base + (size_t)l * pull_stride + (ptrdiff_t)Xs[cx + 1] * pull_pc;
       raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
     });
     if constexpr (HASBC != 0) {
@@ -647,23 +667,23 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
       });
     }
     if constexpr (SW) {
-      // the two outermost cells of the row on either side feed the strips: 16 values per population and plane
-      // ([row][e]: c_z = -1 -> columns 0, 1 (left edge); c_z = +1 -> columns TZ - 2, TZ - 1 (right edge); c_z = 0 -> column 0
-      // (left edge) and column TZ - 1 (right edge)), staged in LDS and written out by the waves without output cells
+      // the two outermost cells of the row on either side feed the strips.  Each of those four lanes parks ALL its Q values in LDS
+      // ([edge lane 0..3][row][population]: one exec-masked region, Q plain writes — selecting per population what the strips
+      // need cost ~200 instructions per wave and plane, +20 % on the periodic box); the waves without output cells pick the 16
+      // values per population the strips hold (c_z = -1: columns 0, 1; c_z = +1: columns TZ - 2, TZ - 1; c_z = 0: columns 0 and
+      // TZ - 1) and write them out
       if (kb < 2 || kb >= TZ - 2) {
-        S* stg = strip_stage + (d & 1) * (Q * 16) + jb * 2;
-        static_for<Q>([&](auto lc) {
-          constexpr int l = decltype(lc)::value;
-          constexpr int cz = L::c(2, l);
-          const S v = to_store<S, T>(f[l]);
-          if constexpr (cz == -1) {
-            if (kb < 2) stg[l * 16 + kb] = v;
-          } else if constexpr (cz == 1) {
-            if (kb >= TZ - 2) stg[l * 16 + kb - (TZ - 2)] = v;
-          } else {
-            if (kb == 0) stg[l * 16] = v;
-            if (kb == TZ - 1) stg[l * 16 + 1] = v;
-          }
+        // slot k of an edge lane: k < NZ1: its c_z = -1 (left lanes) / c_z = +1 (right lanes) populations in index order, then the c_z = 0 ones
+        constexpr int NZ1 = (Q - n_cz0<L>()) / 2, NSLOT = NZ1 + n_cz0<L>();
+        const bool left = kb < 2;
+        S* stg = strip_stage + (d & 1) * (NSLOT * 4 * TY) + ((left ? kb : kb - (TZ - 4)) * TY + jb) * NSLOT;
+        static_for<NZ1>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          stg[k] = to_store<S, T>(left ? f[nth_cz<L>(-1, k)] : f[nth_cz<L>(1, k)]);
+        });
+        static_for<n_cz0<L>()>([&](auto kc) {
+          constexpr int k = decltype(kc)::value;
+          stg[NZ1 + k] = to_store<S, T>(f[nth_cz<L>(0, k)]);
         });
       }
     }
@@ -688,7 +708,14 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
           const int cz = (int)((CZP >> l) & 1u) - (int)((CZM >> l) & 1u);
           const unsigned b = cz < 0 ? bL : (cz > 0 ? bR : (e == 0 ? bL : bR));
           const unsigned j = cz != 0 ? (unsigned)e : (e == 0 ? 1u : 0u);
-          const S v = strip_stage[(d & 1) * (Q * 16) + l * 16 + i];
+          // edge lane that produced it: c_z = -1 -> column e (lanes 0, 1); c_z = +1 -> column TZ - 2 + e (lanes 2, 3); c_z = 0 -> column 0 / TZ - 1;
+          // slot: position of l among the populations of its c_z class (+ NZ1 for c_z = 0)
+          constexpr int NZ1 = (Q - n_cz0<L>()) / 2, NSLOT = NZ1 + n_cz0<L>();
+          constexpr unsigned CZ0 = ((1u << Q) - 1u) & ~(CZP | CZM);
+          const int lane4 = cz < 0 ? e : (cz > 0 ? 2 + e : (e == 0 ? 0 : 3));
+          const unsigned below = (1u << l) - 1u;
+          const int k = cz < 0 ? __builtin_popcount(CZM & below) : (cz > 0 ? __builtin_popcount(CZP & below) : NZ1 + __builtin_popcount(CZ0 & below));
+          const S v = strip_stage[(d & 1) * (NSLOT * 4 * TY) + (lane4 * TY + r) * NSLOT + k];
           a.strips_dst[(((ptrdiff_t)((size_t)l * a.plane_stride) + (ptrdiff_t)x * pc) >> 5) + (ptrdiff_t)(((size_t)b * (unsigned)ny + (unsigned)yy) * 2u + j)] = v;
         }
       }
@@ -757,8 +784,10 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
   __shared__ S lds[G::RING_PLANES * G::NE + G::STAGE_ELEMS];                          // the ring of f(t+1) (D3Q19, 8x64 tile, three-plane layout: 150 480 B -> one block per CU)
   __shared__ unsigned ldsmeta[HASBC ? 3 * G::NE : 1];           // [plane % 3][cell] kind | slot << 4 | missing << 8 of the f(t+1) cells
   __shared__ T bcval[HASBC ? MAX_FAST_BCS * 32 : 1];            // per-BC constants (feq of EquilibriumBC / moving-wall terms), by slot
-  __shared__ S strip_stage[(STRIPS & 2) ? 2 * L::Q * 16 : 1];   // [ring plane & 1][population][row][e]: the plane's strip values on their way out
-  static_assert(G::LDS_BYTES + ((STRIPS & 2) ? 2 * L::Q * 16 * 4 : 0) <= 160 * 1024, "strip staging does not fit the LDS");
+  constexpr int STRIP_SLOTS = (L::Q - n_cz0<L>()) / 2 + n_cz0<L>();  // values an edge cell contributes: its c_z = -1 or +1 populations and the c_z = 0 ones
+  __shared__ S strip_stage[(STRIPS & 2) ? 2 * STRIP_SLOTS * 4 * TY : 1];   // [ring plane & 1][edge lane][row][slot]: the plane's edge cells on their way to the strips
+  static_assert(TY == 8 || (STRIPS & 2) == 0, "strip staging is laid out for 8-row tiles");
+  static_assert(G::LDS_BYTES + ((STRIPS & 2) ? 2 * STRIP_SLOTS * 4 * TY * 4 : 0) <= 160 * 1024, "strip staging does not fit the LDS");
   if constexpr (HASBC != 0) {
     if (a.clean != nullptr && a.clean[blockIdx.x] != 0) {
       step2_body<L, T, S, COLL, 0, TY, TZ, SLAB, PACKED, XLB_STEP2_CLEAN_GMAX, XLB_PIN_CLEAN, FAST, G::SLACK, STRIPS>(a, lds, ldsmeta, bcval, strip_stage);
