@@ -69,7 +69,7 @@ def test_lattice_tables_in_the_kernels_match_python_without_a_device():
         assert np.array_equal(cc[:, : vs._cc.shape[1]], vs._cc.astype(np.int32))
 
 
-@pytest.mark.parametrize("source", ["step2_d3q19.hip", "step2_d3q19_strips.hip"])
+@pytest.mark.parametrize("source", ["step2_d3q19.hip", "step2_d3q19_strips.hip", "step2_d3q27.hip"])
 def test_two_step_kernel_does_not_spill(tmp_path, source):
     """k_step2 counts its outstanding vector-memory operations by hand (a counted s_waitcnt vmcnt(N) behind inline-asm loads,
     step2_kernel.hpp): a register spill adds scratch loads/stores the count does not know about and may copy a register
@@ -100,7 +100,7 @@ def test_two_step_kernel_does_not_spill(tmp_path, source):
         m = re.fullmatch(r"s_waitcnt vmcnt\((\d+)\)", l.strip())
         if m and int(m.group(1)) > 0 and lines[i - 1].strip() == ";;#ASMSTART":
             waits.append((i, int(m.group(1))))
-    assert len(waits) >= 2, "hand-placed counted vmcnt not found in the boundary-condition variants"
+    assert len(waits) >= (1 if "d3q27" in source else 2), "hand-placed counted vmcnt not found in the boundary-condition variants"
     for w, need in waits:
         stores = 0
         i = w - 2

@@ -164,7 +164,8 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_clean"] = 1;      // two-step kernel with BCs: work items without boundary cells run the BC-free body (same launch)
   c->opts["fuse2_tile"] = 0;       // tile of the two-step kernel: 0 = 8 x 64, 2 = 16 x 32 (D3Q19)
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
-  c->opts["fuse2_strips"] = 1;     // two-step kernel (D3Q19): halo columns of phase A from the fields' strip buffers (step2_kernel.hpp); 0 = plain pulls
+  c->opts["fuse2_strips"] = 1;     // two-step kernel (D3Q19): halo columns of phase A from the fields' strip buffers (step2_kernel.hpp): 0 never,
+                                   // 1 = for steppers with boundary conditions (where they pay), 2 = always
   c->opts["fast_bgk"] = 0;         // two-step kernel: 1 = tolerance-graded fast BGK body (rounding-level differences; +2-4 %)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
@@ -1132,7 +1133,8 @@ static StepLaunch make_launch(xlbhip_stepper* s, const xlbhip_field* src, xlbhip
   p.tile_tz = fuse2_tile_tz(c);
   // D3Q27 KBC: (8 x 48) tiles — 8 waves per block, i.e. 2 per SIMD and 256 VGPRs for the collision (the (8 x 64) tile's 11 waves
   // leave 168: 3.8 KB of scratch in fp64); the grown tile is 500 cells for 384 outputs, the same ratio as (8 x 64)
-  if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) p.tile_tz = 48;
+  // D3Q27 BGK with boundary conditions (round 3): the BC ring — 63 population-planes — fits the LDS on the same (8 x 48) tile: 126 KB
+  if (s->lattice == XLBHIP_D3Q27 && (s->collision == XLBHIP_KBC || (s->n_bc > 0 && bcm))) p.tile_tz = 48;
   p.tab_kind = s->tab_kind;
   p.ids_packed = s->ids_packed;
   p.kinds_packed = s->kinds_packed;
@@ -1231,7 +1233,7 @@ static void drop_clean_cache(xlbhip_stepper* s) {
 }
 
 static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
-  if (s->lattice == XLBHIP_D3Q27) return s->collision == XLBHIP_KBC ? launch_step2_d3q27_kbc(p) : launch_step2_d3q27_bgk(p);
+  if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) return launch_step2_d3q27_kbc(p);
   p.clean = nullptr;
   if (p.has_bc && p.meta && opt(s->ctx, "fuse2_clean", 1)) {
     // everything the block -> (tile, x-segment) mapping depends on: the flags say "no boundary cell in THIS block's item"
@@ -1249,6 +1251,7 @@ static int launch_step2(xlbhip_stepper* s, StepLaunch p) {
     }
     p.clean = it->second;
   }
+  if (s->lattice == XLBHIP_D3Q27) return launch_step2_d3q27_bgk(p);
   return p.strips ? launch_step2_d3q19_bgk_strips(p) : launch_step2_d3q19_bgk(p);
 }
 
@@ -1354,7 +1357,11 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   // bit-exact body, (8 x 64) tiles; a field whose strips are not those of its current contents gets them rebuilt first.
   xlbhip_field* srcw = const_cast<xlbhip_field*>(src);
   const bool native_slab = src->halo > 0 && !opt(c, "external_halo", 0);
-  const bool strips = opt(c, "fuse2_strips", 1) != 0 && s->lattice == XLBHIP_D3Q19 && !p.fast_bgk && p.tile_ty == 8 && p.tile_tz == 64 &&
+  // With boundary conditions only: there they buy 1-3 % (cavity 512^3, interleaved A/B: halfway 2.353 -> 2.334, fullway 2.220 -> 2.149
+  // ms/step); the BC-free kernel is faster with row-aligned lanes alone (2.12 against 2.18 with strips, 2.29 before: profiles/r03/step2_strips.md).
+  // fuse2_strips = 2 forces them for every D3Q19 stepper.
+  const int64_t strips_opt = opt(c, "fuse2_strips", 1);
+  const bool strips = (strips_opt == 2 || (strips_opt == 1 && p.has_bc)) && s->lattice == XLBHIP_D3Q19 && !p.fast_bgk && p.tile_ty == 8 && p.tile_tz == 64 &&
                       (src->halo == 0 || native_slab) && src->nx >= 8 && ensure_strips(srcw) && ensure_strips(dst);
   auto read_strips = [&](StepLaunch& q) -> int {  // q reads src's strips (all interior planes) and writes dst's
     if (srcw->strips_version != srcw->version || srcw->strips_oz != q.tile_oz) {
@@ -1504,7 +1511,9 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
     s->meta_cells = cells;
     s->meta_bc = nullptr;  // (contents gone: rebuild below)
   }
-  const int tys = bcm->ny / fuse2_tile_ty(c), tzs = bcm->nz / fuse2_tile_tz(c);
+  // (the tile of THIS stepper: make_launch — D3Q27 with boundary conditions marches (8 x 48) tiles)
+  const int tile_tz = s->lattice == XLBHIP_D3Q27 ? 48 : fuse2_tile_tz(c);
+  const int tys = bcm->ny / fuse2_tile_ty(c), tzs = bcm->nz / tile_tz;
   const bool shifted = opt(c, "fuse2_shift", 1) != 0;
   const int order_mode = (opt(c, "fuse2_lpt", 1) == 3 ? 3 : 0) + (shifted ? 8 : 0);
   if (s->order_ty != tys || s->order_tz != tzs || s->order_mode != order_mode) {
@@ -1580,7 +1589,7 @@ static int prepare_fuse2(xlbhip_stepper* s, const xlbhip_field* bcm, const xlbhi
   drop_clean_cache(s);  // (stream-ordered: the flags' last readers were enqueued before this point and hipFree synchronises)
   hipLaunchKernelGGL(k_build_meta, blocks_for(cells), 256, 0, c->stream, static_cast<const uint8_t*>(bcm->data),
                      miss ? static_cast<const uint32_t*>(miss->data) : nullptr, s->meta, cells, s->ids_packed, s->kinds_packed,
-                     s->moving_mask);
+                     s->moving_mask, s->lattice == XLBHIP_D3Q27 ? 1 : 0);
   XLB_HIP(hipGetLastError());
   // slab decomposition: phase A also runs on the ghost planes -1 and nx, so it needs the neighbours' boundary
   // information there.  Host-staged transports (external_halo) fill the ghost planes of the masks themselves.

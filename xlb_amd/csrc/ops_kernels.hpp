@@ -1034,11 +1034,11 @@ __global__ void k_gather(const E* data, size_t plane_stride, size_t ghost, int c
   for (int l = 0; l < card; ++l) out[i * card + l] = data[(size_t)l * plane_stride + ghost + cells[i]];
 }
 
-// meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table:
-//   bits 0-3 kind (0 fluid, XLBHIP_BC_* for the basic kinds, 9 = halfway wall WITH a moving-wall term),
-//   bits 4-7 slot of the BC in the stepper's packed tables, bits 8.. missing bit-set (D3Q19: 19 bits)
+// meta word of the two-step kernel, resolved once per run so that the kernel never searches an id table (layouts: step2_kernel.hpp
+// S2Meta): kind (0 fluid, XLBHIP_BC_* for the basic kinds, or "halfway wall WITH a moving-wall term"), slot of the BC in the
+// stepper's packed tables, missing bit-set.  wide = 0: 4 + 4 + up to 24 bits (D3Q19); wide = 1: 3 + 3 + bits 1 .. 26 (D3Q27).
 __global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* meta, size_t n, unsigned long long ids_packed,
-                             unsigned kinds_packed, unsigned moving_mask) {
+                             unsigned kinds_packed, unsigned moving_mask, int wide) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned id = bc[i];
@@ -1050,8 +1050,14 @@ __global__ void k_build_meta(const uint8_t* bc, const uint32_t* miss, uint32_t* 
         kind = (kinds_packed >> (4 * s)) & 0xfu;
         slot = (unsigned)s;
       }
-    if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 15u;  // K_HW_MOVING (step2_kernel.hpp)
-    w = kind | (slot << 4) | ((miss ? miss[i] : 0u) << 8);
+    const unsigned m = miss ? miss[i] : 0u;
+    if (wide) {
+      if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 5u;  // S2Meta<D3Q27>::K_HWM
+      w = (kind & 7u) | (slot << 3) | ((m >> 1) << 6);
+    } else {
+      if (kind == XLBHIP_BC_HALFWAY_BB && ((moving_mask >> slot) & 1u)) kind = 15u;  // S2Meta<D3Q19>::K_HWM
+      w = kind | (slot << 4) | (m << 8);
+    }
   }
   meta[i] = w;
 }

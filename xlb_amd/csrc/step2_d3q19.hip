@@ -10,9 +10,11 @@ bool step2_eligible(const StepLaunch& p, int lattice, int collision) {
   for (int i = 0; i < p.n_bc && i < 8; ++i)
     if (((p.kinds_packed >> (4 * i)) & 0xfu) == XLBHIP_BC_DO_NOTHING && !p.edge_ext) return false;
   if (!(p.store_dtype == XLBHIP_F32 && p.nx >= 4 && p.ny % p.tile_ty == 0 && p.nz % p.tile_tz == 0)) return false;
-  if (lattice == XLBHIP_D3Q27) {  // built without boundary conditions and without ghost planes only (LDS: 54 population-planes)
-    if (!(p.has_bc == 0 && p.halo == 0 && p.tile_ty == 8)) return false;
-    if (collision == XLBHIP_BGK) return p.compute_dtype == XLBHIP_F32 && p.tile_tz == 64;
+  if (lattice == XLBHIP_D3Q27) {  // without ghost planes only; BGK also with the basic boundary conditions, on (8 x 48) tiles (63 population-planes)
+    if (!(p.halo == 0 && p.tile_ty == 8)) return false;
+    if (collision == XLBHIP_BGK)
+      return p.compute_dtype == XLBHIP_F32 && (p.has_bc == 0 ? p.tile_tz == 64 : (p.has_bc == 1 && p.tile_tz == 48 && p.n_bc <= MAX_FAST_BCS));
+    if (p.has_bc != 0) return false;
     // KBC: fp32 and fp64 compute, (8 x 48) tiles (api.hip make_launch)
     // (the bit-exact fp64 collision needs 940 B of scratch there — 12 ms per step: it stays on the single-step kernel)
     return collision == XLBHIP_KBC && (p.compute_dtype == XLBHIP_F32 || (p.compute_dtype == XLBHIP_F64 && p.fast_math)) && p.tile_tz == 48;
@@ -43,11 +45,14 @@ int launch_step2_d3q19_bgk(const StepLaunch& p) {
 
 // per-block "no boundary cell in this work item" flags for the launch geometry of p (n = tiles x effective segments bytes)
 int step2_build_clean(const StepLaunch& p, uint8_t* out) {
-  XLB_REQUIRE(p.meta && out && p.tile_ty == 8 && p.tile_tz == 64, "clean flags: (8 x 64) tiles with meta words only");
+  XLB_REQUIRE(p.meta && out && p.tile_ty == 8 && (p.tile_tz == 64 || (p.tile_tz == 48 && p.halo == 0)), "clean flags: (8 x 64) / (8 x 48) tiles with meta words only");
   const size_t ghost = (size_t)p.halo * p.ny * p.nz;
-  const unsigned tiles = (unsigned)(p.ny / 8) * (unsigned)(p.nz / 64);
+  const unsigned tiles = (unsigned)(p.ny / 8) * (unsigned)(p.nz / p.tile_tz);
   const int segs = step2_eff_segments(p), swz = step2_eff_swizzle(p, tiles);
-  if (p.halo)
+  if (p.tile_tz == 48)
+    hipLaunchKernelGGL((k_step2_clean<8, 48, false>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
+                       p.x_count, p.nx, p.ny, p.nz, p.tile_oy, p.tile_oz, out);
+  else if (p.halo)
     hipLaunchKernelGGL((k_step2_clean<8, 64, true>), dim3(tiles * (unsigned)segs), dim3(256), 0, p.stream, p.meta + ghost, p.tile_order, swz, segs, step2_eff_cap(p), p.x_begin,
                        p.x_count, p.nx, p.ny, p.nz, p.tile_oy, p.tile_oz, out);
   else

@@ -174,9 +174,20 @@ struct S2Geom {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // meta word (built per run by k_build_meta): kind | slot << 4 | missing << 8
-constexpr unsigned K_HW_MOVING = 15;  // internal to the meta word (4 bits); the public kinds end at 9
-__device__ __forceinline__ unsigned meta_kind(unsigned w) { return w & 0xfu; }
-__device__ __forceinline__ unsigned meta_slot(unsigned w) { return (w >> 4) & 0xfu; }
+// Two layouts of the 32 bits (k_build_meta, ops_kernels.hpp, writes them):
+//   up to 24 populations (D3Q19): kind in bits 0-3, slot in 4-7, the missing bit-set from bit 8;
+//   D3Q27 ("wide"): kind in bits 0-2, slot in 3-5, missing bits 1 .. 26 from bit 6.  Bit 0 — the rest population — is dropped:
+//   it is only ever set at solid cells given by interior indices, where a halfway wall "redirects" f_0 to the own cell's f_0.
+// The halfway wall WITH a moving-wall term is a kind of its own inside the word (15, wide: 5); the public kinds it can hold end at 3.
+template <class L>
+struct S2Meta {
+  static constexpr bool WIDE = L::Q > 24;
+  static constexpr unsigned KBITS = WIDE ? 3 : 4, MSHIFT = 2 * KBITS;
+  static constexpr unsigned K_HWM = WIDE ? 5u : 15u;
+  static __device__ __forceinline__ unsigned kind(unsigned w) { return w & ((1u << KBITS) - 1u); }
+  static __device__ __forceinline__ unsigned slot(unsigned w) { return (w >> KBITS) & ((1u << KBITS) - 1u); }
+  static __device__ __forceinline__ unsigned missing(unsigned w) { return WIDE ? (w >> MSHIFT) << 1 : w >> MSHIFT; }
+};
 
 // Union over the wave of the missing bits of its halfway-wall lanes, as a UNIFORM (scalar) word: 0 for a fluid
 // wave; for a z-face wave 5 of 19 bits.  One scalar test of it separates fluid waves (straight-line code) from
@@ -231,6 +242,7 @@ template <class L, class T, class S, int COLL, int HASBC, int TY, int TZ, bool S
 __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsigned* ldsmeta, T* bcval, S* strip_stage = nullptr) {
   using G = S2Geom<L, HASBC, TY, TZ, PACKED>;
   using R = S2Ring<L, HASBC, PACKED, SLACK>;
+  using M = S2Meta<L>;
   constexpr int Q = L::Q, NE = G::NE, EZ = G::EZ;
   constexpr unsigned ES = sizeof(S);
 #if defined(XLB_STRIPS_NOREAD)  // measurement builds (tools/r03_call4.sh): one half of the mechanism at a time
@@ -435,8 +447,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) __attribute__((always_inline)) {
     mall = 0;
     if constexpr (HASBC != 0) {
-      const unsigned kind_ = meta_kind(w);
-      mall = wave_or((act_a && (kind_ == K_HW || kind_ == K_HW_MOVING)) ? (w >> 8) : 0u);  // all lanes active here
+      const unsigned kind_ = M::kind(w);
+      mall = wave_or((act_a && (kind_ == K_HW || kind_ == M::K_HWM)) ? M::missing(w) : 0u);  // all lanes active here
     }
     if (!act_a) return;  // only the tail of the last wave is idle
     int Xs[3];  // storage planes of the sources (index c_x + 1 -> plane x - c_x)
@@ -456,8 +468,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
       // directions; do-nothing: own cell, same population) go out as inline-asm loads into fix[]: hipcc's
       // s_waitcnt bookkeeping does not see them, so this divergent region leaves the vmcnt model of the
       // steady-state loop exact (see the note above).  finish_a waits for them by hand.
-      const unsigned kind = meta_kind(w), m = w >> 8;
-      const bool hw = kind == K_HW || kind == K_HW_MOVING;
+      const unsigned kind = M::kind(w), m = M::missing(w);
+      const bool hw = kind == K_HW || kind == M::K_HWM;
       if (mall != 0u) {
         const unsigned voff = cell_a * ES;
         static_for<Q>([&](auto lc) {
@@ -487,9 +499,9 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   };
   // boundary kinds that replace whole cells (halfway walls are handled where the pulls are redirected)
   auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) __attribute__((always_inline)) {
-    const unsigned kind = meta_kind(w);
+    const unsigned kind = M::kind(w);
     if (kind == K_EQ) {
-      const T* val = bcval + opaque(meta_slot(w) * 32u);
+      const T* val = bcval + opaque(M::slot(w) * 32u);
       static_for<Q>([&](auto lc) { f[decltype(lc)::value] = val[decltype(lc)::value]; });
     } else if (kind == K_FW) {
       fullway = true;
@@ -507,8 +519,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         f[l] = ((mm >> l) & 1u) ? cand : f[l];
       });
     } else {
-      const T* val = bcval + meta_slot(w) * 32u;
-      const bool mov = meta_kind(w) == K_HW_MOVING;
+      const T* val = bcval + M::slot(w) * 32u;
+      const bool mov = M::kind(w) == M::K_HWM;
       static_for<Q>([&](auto lc) {
         constexpr int l = decltype(lc)::value;
         const T cand = got[l] + (mov ? val[l] : T(0));
@@ -524,8 +536,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      const unsigned kind = meta_kind(w);
-      const bool hw = kind == K_HW || kind == K_HW_MOVING;
+      const unsigned kind = M::kind(w);
+      const bool hw = kind == K_HW || kind == M::K_HWM;
       if (mall != 0u) {  // wave-uniform: some lane of this wave has redirected pulls
         // The fix-up loads are invisible to the compiler: wait for them here (boundary waves only).
         // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
@@ -539,7 +551,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         else
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned mm = hw ? (w >> 8) : 0u;
+        const unsigned mm = hw ? M::missing(w) : 0u;
         T got[Q];
         static_for<Q>([&](auto lc) {
           constexpr int l = decltype(lc)::value;
@@ -547,7 +559,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
           asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
           got[l] = to_compute<T, S>(v);
         });
-        hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(kind == K_HW_MOVING) != 0ull);
+        hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(kind == M::K_HWM) != 0ull);
       }
       if (kind != 0u) bc_regs(f, w, fullway);
     }
@@ -583,8 +595,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     if constexpr (HASBC != 0) w = ldsmeta[(q0 % 3) * NE + ctr_b];
     unsigned mall = 0, mm = 0;
     if constexpr (HASBC != 0) {
-      const unsigned kind = meta_kind(w);
-      mm = (kind == K_HW || kind == K_HW_MOVING) ? (w >> 8) : 0u;
+      const unsigned kind = M::kind(w);
+      mm = (kind == K_HW || kind == M::K_HWM) ? M::missing(w) : 0u;
       mall = wave_or(mm);  // uniform; all lanes of the wave are active here (NB is a whole number of waves)
     }
     if (mall == 0u) {  // fluid wave (or only fullway / equilibrium lanes): one scalar branch, then straight-line reads
@@ -625,11 +637,11 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
         got[l] = to_compute<T, S>(lds[((mm >> l) & 1u) ? idx_own : idx_pull]);
         f[l] = got[l];
       });
-      hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(meta_kind(w) == K_HW_MOVING) != 0ull);
+      hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(M::kind(w) == M::K_HWM) != 0ull);
     }
     bool fullway = false;
     if constexpr (HASBC != 0) {
-      if (meta_kind(w) != 0u) bc_regs(f, w, fullway);
+      if (M::kind(w) != 0u) bc_regs(f, w, fullway);
     }
     finish(f, fullway);
   };
