@@ -1474,6 +1474,9 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // single-step kernel (profiles/r02/d3q27_kbc_two_step.txt)
     // Round 3: with the gamma reduction in fp32 (cell.hpp COLL_G32: fp64 compute, fp32 store — BASELINE configs[4]) the pairs WIN,
     // 2.18 against 2.24 ms per step at 384^3 (profiles/r03/kbc_gamma32.md); fp32 KBC pairs still lose and stay on request.
+    // D3Q27 BGK with boundary conditions (round 3, (8 x 48) tiles, 192 VGPRs): bit-exact, but 2.59 against 2.15 ms per step on the 384^3
+    // cavity (0.59 against 0.71 of the roofline, profiles/r03/d3q27_walls_two_step.md): on request only
+    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_BGK && p.has_bc) return false;
     if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC &&
         !(XLB_KBC_GAMMA32 && p.compute_dtype == XLBHIP_F64 && p.store_dtype == XLBHIP_F32 && p.fast_math))
       return false;
