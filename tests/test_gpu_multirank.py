@@ -35,13 +35,22 @@ def test_ranks_sharing_one_gpu_host_staged_halo(world):
     assert "GPU_SLAB_OK" in out.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_ranks_sharing_one_gpu_ipc_halo(world):
     """The device-to-device transport that does not need RCCL: hipIpc-mapped neighbour fields pulled
     with copies on the communication stream, ordered by counters in host shared memory — with 2 and 3 ranks on ONE GPU
     the whole native slab protocol runs: depth-1 and depth-2 exchanges, chain ends, uneven slabs, overlap on / off, the
-    collective pairing vote, the meta-plane exchange.  Bit-exact against the single-domain oracle."""
+    collective pairing vote, the meta-plane exchange.  Bit-exact against the single-domain oracle.  (4 ranks: with the test runner itself that
+    is as many processes as this pool lets share a card safely — its guard allows 6 and killed a 6-rank attempt.)"""
     out = torchrun("_gpu_rank_worker.py", world, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="ipc")
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "GPU_SLAB_OK" in out.stdout
+
+
+def test_ipc_chain_three_ranks():
+    """periodic_x=False: the ring opened into a chain — what bench.py runs the halfway cavity (BASELINE configs[2] / [3]) with.
+    Rank 0 has no left neighbour, rank 2 no right one, rank 1 both; the result is the ring's, i.e. the single-domain oracle's."""
+    out = torchrun("_gpu_rank_worker.py", 3, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="ipc", XLB_TEST_CHAIN="1")
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     assert "GPU_SLAB_OK" in out.stdout
 
