@@ -1472,14 +1472,10 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // D3Q27 KBC pairs on request only (fuse2 = 2): ~1100 (fp32) / 810 (fast fp64) VALU instructions per cell and 8 waves per CU make
     // the two-step form issue-bound — 384^3: 2.41 (FP64FP32) / 2.52 (FP32FP32) ms per step against 2.21 / 2.16 of the HBM-bound
     // single-step kernel (profiles/r02/d3q27_kbc_two_step.txt)
-    // Round 3: with the gamma reduction in fp32 (cell.hpp COLL_G32: fp64 compute, fp32 store — BASELINE configs[4]) the pairs WIN,
-    // 2.18 against 2.24 ms per step at 384^3 (profiles/r03/kbc_gamma32.md); fp32 KBC pairs still lose and stay on request.
-    // D3Q27 BGK with boundary conditions (round 3, (8 x 48) tiles, 192 VGPRs): bit-exact, but 2.59 against 2.15 ms per step on the 384^3
-    // cavity (0.59 against 0.71 of the roofline, profiles/r03/d3q27_walls_two_step.md): on request only
-    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_BGK && p.has_bc) return false;
-    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC &&
-        !(XLB_KBC_GAMMA32 && p.compute_dtype == XLBHIP_F64 && p.store_dtype == XLBHIP_F32 && p.fast_math))
-      return false;
+    // Round 3: the gamma reduction in fp32 (cell.hpp COLL_G32) speeds the fp64 / fp32-store pairs up by 5.6 % — and single steps by 3.1 % —
+    // on a non-trivial state: pairs 2.28 against 2.23 ms per step at 384^3, still behind (profiles/r03/kbc_gamma32.md; on a uniform
+    // f = w the pairs look 3 % FASTER than single steps: identical operands in every lane, higher clocks — not a state to time on).
+    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) return false;
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
     const long items = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz) * fuse2_segments(s, p), cus = fill_cus(s->ctx);
