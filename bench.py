@@ -93,9 +93,13 @@ def launch(args, argv):
     port = free_port()
     base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XLB_JOB_ID=f"bench-{os.getpid()}-{port}",
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    if os.environ.get("XLB_BENCH_TRANSPORT", "auto") == "host" or (os.environ.get("XLB_BENCH_TRANSPORT", "auto") in ("ipc", "ipc_or_host")
-                                                                   and visible_gpus() < n):
-        base.setdefault("XLB_HIP_DEVICE", "0")  # rehearsal: every rank on ONE GPU (RCCL refuses that; ipc and host do not)
+    have = visible_gpus()
+    if os.environ.get("XLB_BENCH_TRANSPORT", "auto") == "host" or 0 < have < n:
+        # fewer GPUs than ranks (or the host-staged debugging transport): a REHEARSAL with every rank on one GPU — RCCL refuses
+        # that ("Duplicate GPU"), so "auto" ends up on the ipc transport; the JSON line says so
+        if "XLB_HIP_DEVICE" not in base:
+            sys.stderr.write(f"bench.py launcher: {have} GPU(s) visible for {n} ranks: all ranks share device 0 (rehearsal, not a scaling measurement)\n")
+        base.setdefault("XLB_HIP_DEVICE", "0")
     procs = []
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
