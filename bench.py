@@ -72,14 +72,18 @@ def visible_gpus():
     """GPUs this process would see, counted without touching HIP (the launcher must not initialise it): KFD topology
     nodes with compute units, capped by a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list."""
     n = 0
+    top = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        top = "/sys/class/kfd/kfd/topology/nodes"
-        for node in os.listdir(top):
+        nodes = os.listdir(top)
+    except OSError:
+        return 0
+    for node in nodes:
+        try:  # (a container that leases one GPU of a host sees every node but may read only its own: "Operation not permitted")
             for line in open(os.path.join(top, node, "properties")):
                 if line.startswith("simd_count") and int(line.split()[1]) > 0:
                     n += 1
-    except OSError:
-        return 0
+        except OSError:
+            continue
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var, "").strip()
         if v:

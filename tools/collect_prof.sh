@@ -14,4 +14,4 @@ cp ${stats[0]} ${N}_kernel_stats.csv
 grep -h '^{"metric"' $D/kt.log | tail -1 > ${N}_bench_under_rocprof.json
 # the kernel the summary names first must be in the CSV too (same instantiation, same run)
 k=$(grep -m1 -o '`k_step[^`]*`' ${N}_summary.md | tr -d '`' | cut -c1-60)
-grep -q -F "$k" ${N}_kernel_stats.csv || { echo "collect_prof.sh: '$k' of the summary is not in the kernel-stats CSV" >&2; exit 1; }
+sed 's/xlb:://g; s/void //g' ${N}_kernel_stats.csv | grep -q -F "$k" || { echo "collect_prof.sh: '$k' of the summary is not in the kernel-stats CSV" >&2; exit 1; }
