@@ -395,6 +395,7 @@ def main():
         u.free()
     omega = args.omega
 
+    xdist.barrier()  # (set-up takes the ranks unevenly long; the first exchange's bounded waits should not have to cover that)
     f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, args.warmup)
     ctx.sync()
     xdist.barrier()

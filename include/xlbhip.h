@@ -302,7 +302,7 @@ int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_byte
  * default: 8 blocks per plane, no LDS) or by plane-sized hipMemcpyAsync calls (= 0: copy engines, no compute unit;
  * "or hipMemcpyPeerAsync ... over xGMI").  Processes are ordered by sequence counters in a host
  * shared-memory control block /dev/shm/xlbhip-ipc-<token> (created by rank 0, unlinked as soon as every rank mapped
- * it) that one-lane kernels post and poll; every wait is bounded by the option "ipc_timeout_ms" (a timed-out wait
+ * it) that one-lane kernels post and poll; every wait is bounded by the option "ipc_timeout_ms" (default 180 s; a timed-out wait
  * makes the next xlbhip_sync fail).  One node; the ranks may share a device.  `token`: letters / digits / '-' / '_',
  * fresh per job (the host side broadcasts a random one).  Ranks must exchange the same buffers in the same order. */
 int xlbhip_comm_init_ipc(xlbhip_ctx* ctx, int rank, int n_ranks, const char* token, int periodic_x);

@@ -81,3 +81,18 @@ def test_two_ranks_rccl():
         pytest.skip("RCCL refuses two ranks on one device (one-GPU box)")
     assert out.returncode == 0, text[-3000:]
     assert "GPU_SLAB_OK" in out.stdout
+
+
+def test_config3_global_domain_decomposed_matches_one_rank(tmp_path):
+    """BASELINE configs[3] names 8 GPUs; this pool has one.  What CAN be exercised is its global domain and its decomposition: the
+    4096 x 512 x 512 halfway cavity (1.07 G cells, 163 GB of populations) is advanced 7 steps by one rank and then, slab-decomposed,
+    by FOUR ranks (with the test runner the most processes the pool lets share a card) of 1024 planes each that exchange their ghost
+    planes device to device over the ipc transport — fused pairs with the depth-2 exchange, interior / edge launches, strip buffers,
+    then a single step with the depth-1 exchange.  Every population plane checked — the x walls, both sides of every rank boundary,
+    planes in between — is the one-rank run's, bit for bit.  ("configs[3] ... never the decomposition".)"""
+    path = str(tmp_path / "config3_planes.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", XLB_C3_FILE=path, XLB_HIP_DEVICE="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_gpu_config3_worker.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0 and "CONFIG3_REF_OK" in one.stdout, (one.stdout + one.stderr)[-3000:]
+    out = torchrun("_gpu_config3_worker.py", 4, XLB_HIP_DEVICE="0", XLB_TEST_TRANSPORT="ipc", XLB_C3_FILE=path)
+    assert out.returncode == 0 and "CONFIG3_DECOMPOSED_OK" in out.stdout, (out.stdout + out.stderr)[-3000:]

@@ -172,7 +172,8 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["halo_telemetry"] = 1;   // slab runs: time the compute stream's wait for the halo event (xlbhip_comm_stats)
   c->opts["ipc_copy"] = 1;         // ipc transport: 1 = one pull kernel per exchange (8 blocks per plane, no LDS: hidden behind the interior launch),
                                    // 0 = plane-sized hipMemcpyAsync pulls (copy engines; ~40 us per call on a shared device: profiles/r03/ipc_transport.md)
-  c->opts["ipc_timeout_ms"] = 60000;  // ipc transport: bound of every device-side / host-side wait for a neighbour
+  c->opts["ipc_timeout_ms"] = 180000;  // ipc transport: bound of every device-side / host-side wait for a neighbour (ranks reach their first
+                                       // exchange as unevenly as their set-up takes: callers should put a barrier in front of the first run)
   c->opts["halo_skip"] = 0;        // 1: MEASUREMENT ONLY — the slab protocol's launches without moving any ghost plane (wrong results)
   c->opts["comm_self_test"] = 0;   // 1: a one-rank RCCL communicator also runs the all-reduce of comm_all_min (tests)
   *out = c;

@@ -527,7 +527,7 @@ int xlbhip_comm_init_ipc(xlbhip_ctx* c, int rank, int n_ranks, const char* token
   const size_t page = (size_t)sysconf(_SC_PAGESIZE);
   size_t bytes = sizeof(IpcHeader) + (size_t)n_ranks * sizeof(IpcRank);
   bytes = (bytes + page - 1) / page * page;
-  const double timeout_s = (double)opt(c, "ipc_timeout_ms", 60000) * 1e-3;
+  const double timeout_s = (double)opt(c, "ipc_timeout_ms", 180000) * 1e-3;
   int fd = -1;
   const double t0 = now_s();
   if (rank == 0) {
