@@ -7,8 +7,3 @@ step r3_prof_periodic_512 500 bash tools/profile.sh r03_periodic_512 --workload 
 step r3_prof_periodic_256 400 bash tools/profile.sh r03_periodic_256 --workload periodic --size 256
 step r3_prof_kbc 500 bash tools/profile.sh r03_d3q27_kbc_384_fp64fp32 --workload periodic --size 384 --lattice D3Q27 --collision KBC --policy FP64FP32 --omega 1.9 --steps 100
 step r3_prof_d3q27 500 bash tools/profile.sh r03_d3q27_bgk_384_two_step --workload periodic --size 384 --lattice D3Q27 --steps 100
-# the widest rehearsal the pool allows safely (its guard: 6 processes per card): FIVE ranks x 512^3 (2560 x 512 x 512 global, the
-# per-rank size of configs[3]) sharing one MI355X over the ipc transport
-XLB_BENCH_TRANSPORT=ipc step r3_final_ipc5_512 900 python bench.py --gpus 5 --size 512 --steps 12 --warmup 4 --cpu-baseline-seconds 0
-step r3_final_auto2_256 300 python bench.py --gpus 2 --size 256 --steps 40 --cpu-baseline-seconds 0
-step r3_final_multirank 900 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu
