@@ -20,5 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- python3 $ROOT/tools/copy_bw.py 512 3 > $OUT/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- python3 $ROOT/tools/copy_bw.py 512 3 > $OUT/cal_write.log 2>&1
 python3 $ROOT/tools/summarize_prof.py $OUT > $OUT/summary.md 2>&1 || true
+# the stats file of THIS run (the directory was empty when it started), for tools/collect_prof.sh: gpurun merges a run's files INTO the
+# caller's gpurun_out/, where an earlier run's files of the same tag may still lie
+(cd $OUT && find kt -name "*kernel_stats.csv") > $OUT/kt_stats_of_this_run.txt
 find $OUT -name '*.csv' -size +2M -delete
 cat $OUT/summary.md
