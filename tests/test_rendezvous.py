@@ -91,3 +91,37 @@ def test_bench_launcher_propagates_failure():
                          capture_output=True, text=True, timeout=300, env=dict(env, XLB_RDV_TIMEOUT="20"))
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def _chain(scenario):
+    port = free_port()
+    worker = os.path.join(ROOT, "tests", "_chain_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), XLB_CHAIN_SCENARIO=scenario)
+        procs.append(subprocess.Popen([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    return [[l for l in o[0].splitlines() if l.startswith("CHAIN")][0] for o in outs]
+
+
+def test_transport_chain_rccl_fails_on_one_rank_everybody_moves_to_ipc():
+    """bench.py joins with transport="auto": RCCL, then ipc, then host.  A transport that fails on ANY rank is dropped by ALL ranks
+    (a rank that kept it would wait for the others forever) — here RCCL refuses rank 1 only; both ranks tear it down, bring ipc up,
+    pass its self-check and report the same transport string."""
+    lines = _chain("rccl_fails_on_rank1")
+    assert all("transport='ipc (fallback: rccl: rank 1: ncclCommInitRank failed: Duplicate GPU detected)'" in l and "external_halo=0" in l for l in lines), lines
+    assert "calls=rccl,destroy,ipc,verify" in lines[0] and "calls=rccl,destroy,ipc,verify" in lines[1]
+
+
+def test_transport_chain_ends_on_the_host_transport_when_everything_fails():
+    """RCCL comes up but its self-check finds wrong bytes on rank 0; ipc cannot export memory on rank 0: both ranks end on the
+    host-staged transport (external_halo = 1), with both reasons in the transport string."""
+    lines = _chain("all_fail")
+    for l in lines:
+        assert "transport='host (fallback: rccl: rank 0: rccl self-check: ghost plane 1" in l and "ipc: rank 0: hipIpcGetMemHandle" in l and "external_halo=1" in l, l
+
+
+def test_forced_transport_failure_raises_on_every_rank():
+    lines = _chain("forced_ipc_fails")
+    assert all("raised halo transport 'ipc' failed: rank 0: hipIpcGetMemHandle: invalid argument" in l for l in lines), lines
