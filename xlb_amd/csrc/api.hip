@@ -1615,11 +1615,16 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
   }
   // slab protocol: ghosts of src are (re)filled from the ring neighbours on the comm stream while
   // the planes that do not touch a ghost are updated; the two edge planes follow.
-  const bool overlap = opt(c, "overlap", 1) != 0 && src->nx > 2;
+  // The launch that runs BEFORE this step's exchange has completed must not write a plane a neighbour may still be pulling
+  // (ipc transport: the puller, not the owner, knows when a pull is done; what orders the two is that the owner's edge launches
+  // wait for the NEXT exchange, which the neighbour posts after its pulls).  On fields with two ghost planes the previous exchange
+  // may have been a fused pair's — planes 0, 1, nx - 2, nx - 1 of `dst` lent out — so their "edge" is two planes wide.
+  const int edge = src->halo >= 2 ? 2 : 1;
+  const bool overlap = opt(c, "overlap", 1) != 0 && src->nx > 2 * edge;
   XLB_HIP(hipEventRecord(c->ev_edge, c->stream));  // src complete (previous step)
   if (overlap) {  // interior first, then the exchange is posted (see step_twice)
-    p.x_begin = 1;
-    p.x_count = src->nx - 2;
+    p.x_begin = edge;
+    p.x_count = src->nx - 2 * edge;
     if (int rc = launch_any(s, p)) return rc;
   }
   XLB_HIP(hipStreamWaitEvent(c->comm_stream, c->ev_edge, 0));
@@ -1628,9 +1633,9 @@ static int step_kernels(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field
   if (overlap) {
     if (int rc = wait_for_halo(c)) return rc;
     p.x_begin = 0;
-    p.x_count = 1;
+    p.x_count = edge;
     if (int rc = launch_any(s, p)) return rc;
-    p.x_begin = src->nx - 1;
+    p.x_begin = src->nx - edge;
     return launch_any(s, p);
   }
   XLB_HIP(hipStreamWaitEvent(c->stream, c->ev_halo, 0));
