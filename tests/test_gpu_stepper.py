@@ -475,7 +475,7 @@ def test_two_step_y_wall_redirect_regression(faces):
 def test_two_step_strip_buffers_follow_the_fields(walls_cls, halo):
     """Strip buffers of the two-step kernel (step2_kernel.hpp; round 3): phase A takes the halo columns of its grown tile from
     the source field's strips, phase B writes the destination's.  The strips are a cache of the field: whatever else writes
-    a field must invalidate them.  One scenario exercises every way in — strips built from the field (k_build_strips),
+    a field must invalidate them.  One scenario exercises every way in — a first pass that only writes strips (its source has none yet),
     strips written by phase B and re-read, a single step in between (k_step writes the field, not its strips), a host upload
     into a field whose strips were valid, a run with the strips switched off and on again, the wide (nz = 128: two tile
     columns, so the halo columns really come from ANOTHER tile's cells) and the slab layout — against the oracle, bit for bit."""

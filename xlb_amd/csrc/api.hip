@@ -1364,14 +1364,13 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
   const int64_t strips_opt = opt(c, "fuse2_strips", 1);
   const bool strips = (strips_opt == 2 || (strips_opt == 1 && p.has_bc)) && s->lattice == XLBHIP_D3Q19 && !p.fast_bgk && p.tile_ty == 8 && p.tile_tz == 64 &&
                       (src->halo == 0 || native_slab) && src->nx >= 8 && ensure_strips(srcw) && ensure_strips(dst);
-  auto read_strips = [&](StepLaunch& q) -> int {  // q reads src's strips (all interior planes) and writes dst's
-    if (srcw->strips_version != srcw->version || srcw->strips_oz != q.tile_oz) {
-      if (int rc = build_strips(q, src->data, srcw->strips, 0, src->nx)) return rc;
-      srcw->strips_version = srcw->version;
-      srcw->strips_oz = q.tile_oz;
-    }
-    q.strips = 3;
-    q.strips_src = srcw->strips;
+  // q writes dst's strips, and reads src's when they are those of src's current contents (all interior planes).  After anything but
+  // a strip-writing pass wrote src — a single step, an upload — the first pass only WRITES strips (no separate rebuild pass: at 512^3
+  // that would cost 1.5 ms, a third of a pair, inside e.g. the driver's 20-step timed region after its 5 warm-up steps).
+  auto read_strips = [&](StepLaunch& q) -> int {
+    const bool valid = srcw->strips_version == srcw->version && srcw->strips_oz == q.tile_oz;
+    q.strips = valid ? 3 : 2;
+    q.strips_src = valid ? srcw->strips : nullptr;
     q.strips_dst = dst->strips;
     return 0;
   };

@@ -817,31 +817,7 @@ __global__ void __attribute__((aligned(XLB_STEP2_ALIGN))) __launch_bounds__((S2G
 // for every population exactly the two values the halo cells left and right of boundary b pull from row (x, y).  Phase B
 // writes them with the field (two cells per row edge, staged through LDS, written by the waves without output cells: +3 %
 // bytes); phase A's last wave — the 2 x EY halo cells — pulls from it: per population and plane 4 sectors instead of ~15.
-// Anything else that writes the field invalidates its strips (api.hip: strips_version); k_build_strips rebuilds them.
-template <class S>
-__global__ void k_build_strips(const S* __restrict__ f, S* __restrict__ strips, size_t plane_stride, int q, int x_begin, int x_count, int ny, int nz,
-                               int tile_oz, unsigned czp, unsigned czm) {
-  // one thread per (population, plane, boundary, row): both values; f / strips point at interior plane 0
-  const int nb = nz / 64;
-  const size_t n = (size_t)q * x_count * nb * ny;
-  const size_t pc = (size_t)ny * nz;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int y = (int)(i % ny);
-    const int b = (int)((i / ny) % nb);
-    const int x = x_begin + (int)((i / ((size_t)ny * nb)) % x_count);
-    const int l = (int)(i / ((size_t)ny * nb * x_count));
-    const int cz = (int)((czp >> l) & 1u) - (int)((czm >> l) & 1u);
-    const ptrdiff_t off = (ptrdiff_t)((size_t)l * plane_stride) + (ptrdiff_t)x * (ptrdiff_t)pc;
-    const S* row = f + off + (size_t)y * nz;
-    S* out = strips + (off >> 5) + ((size_t)b * ny + y) * 2;
-    int z0 = b * 64 + tile_oz - 1 - cz;
-    z0 = z0 < 0 ? z0 + nz : (z0 >= nz ? z0 - nz : z0);
-    const int z1 = z0 + 1 == nz ? 0 : z0 + 1;
-    out[0] = row[z0];
-    out[1] = row[z1];
-  }
-}
-
+// Anything else that writes the field invalidates its strips (api.hip: strips_version); the next pass then only writes them.
 // clean[b] = 1 when no cell of work item b — grown tile (periodic images included), planes x_lo - 1 .. x_hi + 1 as the kernel
 // visits them — carries a boundary condition.  Same block -> (tile, segment) mapping as k_step2; one block per item.
 template <int TY, int TZ, bool SLAB>

@@ -197,7 +197,7 @@ int launch_step_d3q27_kbc_fast64(const StepLaunch& p);
 bool step2_eligible(const StepLaunch& p, int lattice, int collision);
 int launch_step2_d3q19_bgk(const StepLaunch& p);
 int launch_step2_d3q19_bgk_strips(const StepLaunch& p);  // p.strips != 0 (step2_d3q19_strips.hip)
-int build_strips(const StepLaunch& p, const void* field, void* strips, int x_begin, int x_count);
+
 int launch_step2_d3q27_bgk(const StepLaunch& p);
 int launch_step2_d3q27_kbc(const StepLaunch& p);
 int step2_build_clean(const StepLaunch& p, uint8_t* out);

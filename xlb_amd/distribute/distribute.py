@@ -200,7 +200,17 @@ def transport():
 
 
 def shutdown():
-    """Leave the job: close the control-plane sockets (the device communicator dies with the context)."""
+    """Leave the job: tear the device communicator down (the ipc transport tells its neighbours and gives them a moment to finish
+    pulling before this rank's memory goes away), then close the control-plane sockets."""
+    t = _state.get("transport") or ""
+    if t.startswith(("rccl", "ipc")):
+        try:
+            ctx = get_context()
+            ctx.sync()
+            ctx.comm_destroy()
+            ctx.rank, ctx.n_ranks = 0, 1
+        except Exception:  # noqa: BLE001 (leaving anyway)
+            pass
     if _state["rdv"] is not None:
         _state["rdv"].close()
     _state.update(rdv=None, rank=0, world=1, transport=None)
