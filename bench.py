@@ -395,6 +395,22 @@ def main():
         u.free()
     omega = args.omega
 
+    def copy_yardstick():
+        """streaming-copy rate on the same device and buffers (f_1 is scratch: the next step overwrites it entirely)"""
+        f_1.copy_kernel_from(f_0, 16)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            f_1.copy_kernel_from(f_0, 16)
+        ctx.sync()
+        info = f_0.info()
+        return 2 * info["plane_stride"] * vs.q * pp.store_precision.np_dtype(0).itemsize * 5 / (time.perf_counter() - t1) / 1e9
+
+    # (after the timed region by default; XLB_BENCH_YARDSTICK=before was an experiment — does a device that has just streamed 100 GB enter a
+    # short timed region faster? no: the run-to-run spread, 2.35 / 2.50 ms per step on one box, is bimodal either way and moves with
+    # time inside one process on unchanged allocations: tools/alloc_modes.py, profiles/r03/run_to_run_spread.md)
+    yardstick_first = os.environ.get("XLB_BENCH_YARDSTICK", "after") == "before"
+    copy_gbs = copy_yardstick() if (world == 1 and yardstick_first) else None
     xdist.barrier()  # (set-up takes the ranks unevenly long; the first exchange's bounded waits should not have to cover that)
     f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, omega, args.warmup)
     ctx.sync()
@@ -411,17 +427,8 @@ def main():
     stats = ctx.comm_stats() if world > 1 else {"halo_wait_ms": 0.0, "halo_waits": 0}
     halo_wait = xdist.all_gather([round(stats["halo_wait_ms"], 3), int(stats["halo_waits"])])
 
-    # streaming-copy yardstick on the same device and buffers (after the timed region; f_1 is scratch now)
-    copy_gbs = None
-    if world == 1:
-        f_1.copy_kernel_from(f_0, 16)
-        ctx.sync()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            f_1.copy_kernel_from(f_0, 16)
-        ctx.sync()
-        info = f_0.info()
-        copy_gbs = 2 * info["plane_stride"] * vs.q * pp.store_precision.np_dtype(0).itemsize * 5 / (time.perf_counter() - t1) / 1e9
+    if world == 1 and not yardstick_first:
+        copy_gbs = copy_yardstick()
 
     cells_total = float(np.prod(shape))
     local_cells = float(max(slab_bounds(shape[0], r, world)[1] for r in range(world))) * shape[1] * shape[2]
