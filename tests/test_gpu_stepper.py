@@ -522,9 +522,16 @@ def test_two_step_strip_buffers_follow_the_fields(walls_cls, halo):
         f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 4)
         state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 6)
         assert np.array_equal(f_0.numpy(), state)
+        # the measurement variant: row-aligned lanes in the bodies of the BC kernel, no strips
+        ctx.set_option("fuse2_strips", 0)
+        ctx.set_option("fuse2_rowmap", 1)
+        f_0, f_1 = stepper.run(f_0, f_1, bc_mask, missing_mask, 1.5, 4)
+        state = orc.run(state, o_bm, o_mm, obcs, 1.5, lat, 4)
+        assert np.array_equal(f_0.numpy(), state)
     finally:
         ctx.set_option("fuse2", 1)
         ctx.set_option("fuse2_strips", 1)
+        ctx.set_option("fuse2_rowmap", 0)
 
 
 @pytest.mark.parametrize("shape", [(6, 8, 48), (7, 16, 96), (20, 24, 48)])

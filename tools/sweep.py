@@ -43,7 +43,7 @@ def main():
     vs = getattr(xlb_amd.velocity_set, args.lattice)(precision_policy=pp, compute_backend=ComputeBackend.HIP)
     xlb_amd.init(velocity_set=vs, default_backend=ComputeBackend.HIP, default_precision_policy=pp)
     ctx = get_context()
-    defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap", "xcd_swizzle", "nt_load", "fuse2", "fuse2_xcd", "fuse2_lpt", "fuse2_xseg", "exact_math", "fuse2_clean", "fuse2_xcap", "fuse2_shift", "fast_bgk", "fuse2_tile", "fuse2_strips", "halo_skip", "ipc_copy")}
+    defaults = {k: ctx.get_option(k) for k in ("vec", "nt_store", "plane_pad_bytes", "block_threads", "block_tz", "overlap", "xcd_swizzle", "nt_load", "fuse2", "fuse2_xcd", "fuse2_lpt", "fuse2_xseg", "exact_math", "fuse2_clean", "fuse2_xcap", "fuse2_shift", "fast_bgk", "fuse2_tile", "fuse2_strips", "halo_skip", "ipc_copy", "fuse2_rowmap")}
     n = args.size
     if args.self_comm:
         from xlb_amd import _lib

@@ -166,6 +166,7 @@ int xlbhip_create(int device, xlbhip_ctx** out) {
   c->opts["fuse2_cus"] = 0;        // CUs the chip-filling rule of fuse2 = 1 assumes (0 = the device's; tests of the rule)
   c->opts["fuse2_strips"] = 1;     // two-step kernel (D3Q19): halo columns of phase A from the fields' strip buffers (step2_kernel.hpp): 0 never,
                                    // 1 = for steppers with boundary conditions (where they pay), 2 = always
+  c->opts["fuse2_rowmap"] = 0;     // measurement: 1 = the BC kernel's bodies with row-aligned lanes and NO strip buffers (fuse2_strips must be 0)
   c->opts["fast_bgk"] = 0;         // two-step kernel: 1 = tolerance-graded fast BGK body (rounding-level differences; +2-4 %)
   c->opts["exact_math"] = 0;       // 1: bit-exact builds only (fp64 KBC otherwise uses the tolerance-graded fast collision, cell.hpp kbc_fast)
   c->opts["external_halo"] = 0;    // 1: the caller fills the ghost planes before every step (host-staged transports, tests)
@@ -1374,6 +1375,8 @@ static int step_twice(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     q.strips_dst = dst->strips;
     return 0;
   };
+  const bool rowmap_only = !strips && opt(c, "fuse2_rowmap", 0) != 0 && p.has_bc && s->lattice == XLBHIP_D3Q19 && !p.fast_bgk && p.tile_ty == 8 && p.tile_tz == 64;
+  if (rowmap_only) p.strips = 4;
   auto dst_strips_done = [&]() {  // every interior plane of dst was written by strip-writing launches
     dst->strips_version = dst->version;
     dst->strips_oz = p.tile_oz;

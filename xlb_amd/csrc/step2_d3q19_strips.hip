@@ -7,7 +7,11 @@
 namespace xlb {
 
 int launch_step2_d3q19_bgk_strips(const StepLaunch& p) {
-  XLB_REQUIRE(p.tile_ty == 8 && p.tile_tz == 64 && !p.fast_bgk && (p.strips == 2 || p.strips == 3), "strip buffers: (8 x 64) tiles, bit-exact body");
+  XLB_REQUIRE(p.tile_ty == 8 && p.tile_tz == 64 && !p.fast_bgk && (p.strips == 2 || p.strips == 3 || p.strips == 4), "strip buffers: (8 x 64) tiles, bit-exact body");
+  if (p.strips == 4) {  // row-aligned lanes in both bodies of the BC kernel, no strips ("fuse2_rowmap": measurement option)
+    XLB_REQUIRE(p.has_bc, "fuse2_rowmap: the BC-free kernel has row-aligned lanes anyway");
+    return p.halo ? launch2f<D3Q19, 1, 8, 64, true, true, false, float, XLBHIP_BGK, 4>(p) : launch2f<D3Q19, 1, 8, 64, false, true, false, float, XLBHIP_BGK, 4>(p);
+  }
   if (p.halo) {
     if (p.strips == 3) return p.has_bc ? launch2f<D3Q19, 1, 8, 64, true, true, false, float, XLBHIP_BGK, 3>(p) : launch2f<D3Q19, 0, 8, 64, true, true, false, float, XLBHIP_BGK, 3>(p);
     return p.has_bc ? launch2f<D3Q19, 1, 8, 64, true, true, false, float, XLBHIP_BGK, 2>(p) : launch2f<D3Q19, 0, 8, 64, true, true, false, float, XLBHIP_BGK, 2>(p);

@@ -252,6 +252,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
 #else
   constexpr bool SR = (STRIPS & 1) != 0, SW = (STRIPS & 2) != 0;
 #endif
+  static_assert(STRIPS == 0 || STRIPS == 2 || STRIPS == 3 || STRIPS == 4, "STRIPS: 0, 2 (write), 3 (read + write) or 4 (row-aligned lanes only)");
   static_assert(STRIPS == 0 || (TZ == 64 && sizeof(S) == 4), "strip buffers: (TY x 64) tiles, 4-byte store type");
   // f(t+1) lives in LDS in the STORE type: the single-step kernel rounds it to that type on its way through memory, so the
   // ring holds exactly what two single steps would have stored, whatever the compute type (fp64 KBC: FP64FP32)
@@ -313,7 +314,8 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   // piece per pull instead of the tail of one row + the head of the next), the last wave the two halo columns of all rows
   // Row-aligned lanes are the default of the stand-alone BC-free kernel (two barriers per plane): periodic 512^3 2.28 -> 2.11-2.16
   // ms/step in round 3's A/B (round 2 measured -2...3 %); the bodies of the BC kernel lose 0-3 % with it and keep the dense mapping.
-  constexpr bool ROWMAP = (XLB_STEP2_ROWMAP != 0 || SR || (XLB_STEP2_ROWMAP_PLAIN != 0 && HASBC == 0 && !SLACK) ||
+  // (STRIPS & 4: row-aligned lanes for this body WITHOUT strip buffers — the run-time A/B of api.hip's "fuse2_rowmap" option)
+  constexpr bool ROWMAP = (XLB_STEP2_ROWMAP != 0 || SR || (STRIPS & 4) != 0 || (XLB_STEP2_ROWMAP_PLAIN != 0 && HASBC == 0 && !SLACK) ||
                            (XLB_STEP2_ROWMAP_CLEAN != 0 && HASBC == 0 && SLACK)) && TZ == 64;
   // strip buffers: the last wave holds the 2 x EY halo-column cells of the grown tile (ROWMAP) and pulls for them from the
   // strips — the same instructions as every other wave, with the strip buffer's geometry in place of the field's
