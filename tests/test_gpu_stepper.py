@@ -559,6 +559,22 @@ def test_two_step_fusion_d3q27_with_walls(shape, walls_cls, steps):
         ctx.set_option("fuse2", 1)
 
 
+def test_automatic_choice_keeps_d3q27_with_walls_on_single_steps():
+    """fuse2 = 1 (the default) must not pick the D3Q27-with-BCs two-step kernel: it is 20-45 % slower than single steps
+    (profiles/r03/d3q27_walls_two_step.md).  A rule that a later edit of can_fuse2 once dropped silently."""
+    grid, bcs, lat, obcs = hip_cavity_3d((16, 384, 384), HalfwayBounceBackBC, lattice="D3Q27")
+    ctx = get_context()
+    assert ctx.get_option("fuse2") == 1
+    stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
+    f_0, f_1, bc_mask, missing_mask = stepper.prepare_fields()
+    assert not stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    try:
+        ctx.set_option("fuse2", 2)
+        assert stepper._native_stepper().step2_eligible(f_0, f_1, bc_mask, missing_mask)
+    finally:
+        ctx.set_option("fuse2", 1)
+
+
 def test_two_step_fusion_d3q27_all_basic_kinds():
     """... and every kind the two-step kernel evaluates at once — equilibrium lid, fullway wall, resting and MOVING halfway walls
     (the moving one is a kind of its own inside the wide meta word), an interior solid sphere (whose cells carry missing bit 0,

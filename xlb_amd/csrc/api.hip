@@ -1479,6 +1479,9 @@ static bool can_fuse2(xlbhip_stepper* s, const xlbhip_field* src, xlbhip_field* 
     // on a non-trivial state: pairs 2.28 against 2.23 ms per step at 384^3, still behind (profiles/r03/kbc_gamma32.md; on a uniform
     // f = w the pairs look 3 % FASTER than single steps: identical operands in every lane, higher clocks — not a state to time on).
     if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_KBC) return false;
+    // D3Q27 BGK with boundary conditions (round 3, (8 x 48) tiles, 192 VGPRs): bit-exact, but 2.59-3.16 against 2.15-2.19 ms per step on
+    // the 384^3 cavity (0.48-0.59 against 0.70-0.71 of the roofline, profiles/r03/d3q27_walls_two_step.md): on request only
+    if (s->lattice == XLBHIP_D3Q27 && s->collision == XLBHIP_BGK && p.has_bc) return false;
     // one block per CU marches an (8 x 64) tile column segment: the work items must fill the chip in whole
     // rounds (128^3 = 32 tiles x 4 segments would leave half of the 256 CUs idle)
     const long items = (long)(p.ny / p.tile_ty) * (p.nz / p.tile_tz) * fuse2_segments(s, p), cus = fill_cus(s->ctx);
