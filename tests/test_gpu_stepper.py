@@ -562,7 +562,7 @@ def test_two_step_fusion_d3q27_with_walls(shape, walls_cls, steps):
 def test_automatic_choice_keeps_d3q27_with_walls_on_single_steps():
     """fuse2 = 1 (the default) must not pick the D3Q27-with-BCs two-step kernel: it is 20-45 % slower than single steps
     (profiles/r03/d3q27_walls_two_step.md).  A rule that a later edit of can_fuse2 once dropped silently."""
-    grid, bcs, lat, obcs = hip_cavity_3d((16, 384, 384), HalfwayBounceBackBC, lattice="D3Q27")
+    grid, bcs, lat, obcs = hip_cavity_3d((128, 384, 384), HalfwayBounceBackBC, lattice="D3Q27")  # (fills the chip: no other rule of fuse2 = 1 refuses it)
     ctx = get_context()
     assert ctx.get_option("fuse2") == 1
     stepper = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)
