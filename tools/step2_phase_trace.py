@@ -30,6 +30,9 @@ def main():
     xlb_amd.init(vs, ComputeBackend.HIP, pp)
     ctx = get_context()
     ctx.set_option("fuse2", 2)
+    for kv in filter(None, os.environ.get("XLB_TRACE_OPTS", "").split(",")):  # e.g. XLB_TRACE_OPTS=fuse2_strips=0
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     grid = grid_factory((n, n, n))
     bcs = [] if workload == "periodic" else cavity_bcs(grid, HalfwayBounceBackBC, EquilibriumBC)
     st = IncompressibleNavierStokesStepper(grid=grid, boundary_conditions=bcs)

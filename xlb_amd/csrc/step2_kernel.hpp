@@ -63,7 +63,10 @@ namespace xlb {
 // per wave, for one block and a few planes.  2 additionally drains vmcnt at the top of finish_a, which separates "waiting for the pulls"
 // from the collision (and perturbs the pipeline: the stores drain too).
 #ifdef XLB_STEP2_TRACE
-constexpr int TRACE_PLANES = 6, TRACE_EVENTS = 8, TRACE_WAVES = 11, TRACE_FIRST = 40, TRACE_BLOCK = 300;
+#ifndef XLB_STEP2_TRACE_BLOCK
+#define XLB_STEP2_TRACE_BLOCK 300  // (cavity 512^3, 8 x-segments of 512 tile columns, hull tiles first: 522 = a hull tile's second segment, 812 = a clean item)
+#endif
+constexpr int TRACE_PLANES = 6, TRACE_EVENTS = 8, TRACE_WAVES = 11, TRACE_FIRST = 40, TRACE_BLOCK = XLB_STEP2_TRACE_BLOCK;
 static __device__ unsigned long long g_step2_trace[TRACE_PLANES * TRACE_WAVES * TRACE_EVENTS];
 __device__ __forceinline__ void trace_stamp(int d, int e) {
   __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +221,7 @@ __device__ __forceinline__ unsigned slot_of(const StepArgs<T, S>& a, unsigned id
 // SLAB: the fields carry two ghost planes per side and the launcher passes src / dst / meta advanced to interior
 // plane 0, so that plane indices -2 .. nx + 1 address the ghosts directly and x never wraps.  (A compile-time
 // switch: the kernel sits at the SGPR limit — 19 uniform row bases per plane — and a run-time halo offset pushed
-// it into scratch spills, which also broke the hand-counted vmcnt of the fix-up loads.)
+// it into scratch spills.)
 // planes [x_lo, x_hi) of segment `seg` of a tile column.  Uniform cuts, or — x_cap > 0, at least 3 segments — thin first and
 // last segments of x_cap planes: with walls on the x faces only those two segments of an interior tile column contain
 // boundary cells, and everything else of the column runs the BC-free body (k_step2 below).
@@ -442,11 +445,11 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     }
   };
 
-  // phase A, first half: issue the 19 pulls of plane x from f(t) (kept in registers across phase B).
+  // phase A, first half: issue the Q pulls of plane x from f(t) (kept in registers across phase B).
   // Boundary lanes redirect a pull: a halfway wall reads the own cell's OPPOSITE population for its missing
-  // directions, a do-nothing cell its own populations — same register, same number of loads, nothing
-  // dependent later.  Both arms of the wave-uniform branch issue exactly Q loads.
-  auto issue_a = [&](int x, S(&raw)[Q], S(&fix)[Q], unsigned w, unsigned& mall) __attribute__((always_inline)) {
+  // directions — same instruction, same register, nothing dependent later.  Both arms of the wave-uniform
+  // branch issue exactly Q loads.
+  auto issue_a = [&](int x, S(&raw)[Q], unsigned w, unsigned& mall) __attribute__((always_inline)) {
     mall = 0;
     if constexpr (HASBC != 0) {
       const unsigned kind_ = M::kind(w);
@@ -457,6 +460,28 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     Xs[0] = SLAB ? x + 1 : ((x + 1 == nx) ? 0 : x + 1);
     Xs[1] = x;
     Xs[2] = SLAB ? x - 1 : ((x == 0) ? nx - 1 : x - 1);
+    if constexpr (HASBC != 0) {
+      if (mall != 0u) {
+        // Boundary wave (round 3): a halfway-wall lane pulls each of its missing directions from its OWN cell's OPPOSITE population —
+        // inside the same pull instruction, through a per-lane 64-bit address (4 VALU per pull, boundary waves only).  Exactly Q loads
+        // on either side of this wave-uniform branch, all of them visible to the compiler: its vmcnt model of the loop stays exact
+        // WITHOUT round 2's extra inline-asm loads, their hand-counted wait and the no-copy / no-spill invariants they needed —
+        // and a hull tile's pull phase issues 19 instructions instead of 24-29 (profiles/r03/step2_redirect.md).
+        const unsigned kind = M::kind(w);
+        const unsigned m = (kind == K_HW || kind == M::K_HWM) ? M::missing(w) : 0u;
+        const unsigned voff = cell_a * ES;
+        static_for<Q>([&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
+          const S* row = pull_base + (size_t)l * pull_stride + (ptrdiff_t)Xs[cx + 1] * pull_pc;         // uniform
+          const S* own = a.src + (size_t)opp<L>(l) * a.plane_stride + (ptrdiff_t)x * pc;                // uniform (the field itself, also for the halo wave of a strip build)
+          const bool red = ((m >> l) & 1u) != 0u;
+          const char* p = reinterpret_cast<const char*>(red ? own : row) + (red ? voff : Yb[cy + 1] + Zb[cz + 1]);
+          raw[l] = *reinterpret_cast<const S*>(p);
+        });
+        return;
+      }
+    }
     static_for<Q>([&](auto lc) {
       constexpr int l = decltype(lc)::value;
       constexpr int cx = L::c(0, l), cy = L::c(1, l), cz = L::c(2, l);
@@ -465,39 +490,6 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
       const S* row = pull_base + (size_t)l * pull_stride + (ptrdiff_t)Xs[cx + 1] * pull_pc;
       raw[l] = ld(row, Yb[cy + 1] + Zb[cz + 1]);
     });
-    if constexpr (HASBC != 0) {
-      // Redirected pulls of boundary lanes (halfway wall: own cell, OPPOSITE population, for its missing
-      // directions; do-nothing: own cell, same population) go out as inline-asm loads into fix[]: hipcc's
-      // s_waitcnt bookkeeping does not see them, so this divergent region leaves the vmcnt model of the
-      // steady-state loop exact (see the note above).  finish_a waits for them by hand.
-      const unsigned kind = M::kind(w), m = M::missing(w);
-      const bool hw = kind == K_HW || kind == M::K_HWM;
-      if (mall != 0u) {
-        const unsigned voff = cell_a * ES;
-        static_for<Q>([&](auto lc) {
-          constexpr int l = decltype(lc)::value;
-          if (((mall >> l) & 1u) == 0u) return;  // scalar
-          if (hw && ((m >> l) & 1u)) {
-            // uniform (SGPR) base + one 32-bit lane offset: no per-lane 64-bit address arithmetic.
-            // ONE asm statement per population whose output IS fix[l]: any compiler-inserted copy of an
-            // asm-loaded register before the hand-placed wait would read stale data (guide section 5.7), so
-            // there is no initialiser, no second writer and no select on `got`
-            // (tests/test_gpu_stepper.py::test_two_step_fusion_matches_oracle guards this).
-            const S* b_opp = a.src + (size_t)opp<L>(l) * a.plane_stride + (ptrdiff_t)x * pc;
-            S got;
-#ifdef S2_DEBUG_VISIBLE
-            got = ld(b_opp, voff);
-#else
-            // s_nop 4: hipcc's hazard recognizer cannot see inside the string; the base may have just been written
-            // by a VALU (v_readlane of a spilled SGPR / v_readfirstlane), which needs 5 wait states before a VMEM
-            // instruction reads it — without them the load used a garbage address (memory fault on y-walls)
-            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(got) : "v"(voff), "s"(b_opp) : "memory");
-#endif
-            fix[l] = got;
-          }
-        });
-      }
-    }
   };
   // boundary kinds that replace whole cells (halfway walls are handled where the pulls are redirected)
   auto bc_regs = [&](T(&f)[Q], unsigned w, bool& fullway) __attribute__((always_inline)) {
@@ -532,7 +524,7 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   };
   // phase A, second half: BCs + collision -> LDS slot (populations and the cell's meta word)
   // q: plane counted from x_lo - 1 (ring buffers q & 1 and q % 3; meta slot q % 3)
-  auto finish_a = [&](const S(&raw)[Q], const S(&fix)[Q], unsigned w, unsigned mall, int q, bool steady) __attribute__((always_inline)) {
+  auto finish_a = [&](const S(&raw)[Q], unsigned w, unsigned mall, int q) __attribute__((always_inline)) {
     if (!act_a) return;
     T f[Q];
     static_for<Q>([&](auto lc) { f[decltype(lc)::value] = to_compute<T, S>(raw[decltype(lc)::value]); });
@@ -540,28 +532,10 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     if constexpr (HASBC != 0) {
       const unsigned kind = M::kind(w);
       const bool hw = kind == K_HW || kind == M::K_HWM;
-      if (mall != 0u) {  // wave-uniform: some lane of this wave has redirected pulls
-        // The fix-up loads are invisible to the compiler: wait for them here (boundary waves only).
-        // They were issued one plane ago; the only younger vector-memory operations of this wave are the Q
-        // stores of the phase B that just ran (waves that own output cells: N_STORES each) and possibly the meta prefetch,
-        // so vmcnt(N_STORES) retires the fix-ups WITHOUT draining those stores (vmcnt(0) would: +2-3 us per plane,
-        // which made hull tiles 3x slower than fluid tiles).  Extra younger operations only make this safer.
-        static_assert(G::N_STORES <= 63, "vmcnt immediate");
-        // (in the prologue no phase B has run yet: nothing younger, so drain everything)
-        if (steady && __builtin_amdgcn_readfirstlane(t) < G::NB)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::N_STORES) : "memory");  // = the stores phase_b issues per thread, no more
-        else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+      if (mall != 0u) {  // wave-uniform: some halfway-wall lane of this wave had pulls redirected
+        // the redirected values arrived with the pulls (issue_a): f[l] already IS the own cell's opposite population where the bit is set
         const unsigned mm = hw ? M::missing(w) : 0u;
-        T got[Q];
-        static_for<Q>([&](auto lc) {
-          constexpr int l = decltype(lc)::value;
-          S v = fix[l];  // (populations outside `mall` were never loaded: garbage that no lane selects)
-          asm volatile("" : "+v"(v));  // keep the read of fix[l] behind the wait
-          got[l] = to_compute<T, S>(v);
-        });
-        hw_apply(f, got, mm, w, __builtin_amdgcn_ballot_w64(kind == M::K_HWM) != 0ull);
+        hw_apply(f, f, mm, w, __builtin_amdgcn_ballot_w64(kind == M::K_HWM) != 0ull);
       }
       if (kind != 0u) bc_regs(f, w, fullway);
     }
@@ -737,21 +711,17 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
   };
 
   // Plane x_lo + p is plane q = p + 1 of the ring (p = -1: the periodic image / ghost plane below the segment).
-  // (fix[] deliberately has NO initialiser, not even in the prologue: a second writer of a register that an inline-asm load
-  // targets makes hipcc insert a copy right behind the asm statement — before the hand-placed wait, i.e. of stale data.  Lanes
-  // that loaded nothing never select their fix[] value.  tests/test_capi_symbols.py checks the compiled code: no scratch, and
-  // >= 19 stores between the fix-up loads and the counted wait.)
-  S raw[Q], fix[Q];
+  S raw[Q];
   unsigned w_raw = 0, mall_raw = 0;  // meta word / wave union of the plane held in raw
   // prologue: planes -1, 0, 1 straight into the ring (synchronous), then the pulls of plane 2 go in flight.
   for (int p = -1; p <= 1; ++p) {
     if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + p), cell_a);
-    issue_a(wrapx(x_lo + p), raw, fix, w_raw, mall_raw);
+    issue_a(wrapx(x_lo + p), raw, w_raw, mall_raw);
     if (p == -1) __syncthreads();  // bcval ready before the first bc_regs
-    finish_a(raw, fix, w_raw, mall_raw, p + 1, false);
+    finish_a(raw, w_raw, mall_raw, p + 1);
   }
   if constexpr (HASBC != 0) w_raw = meta_load(wrapx(x_lo + 2), cell_a);
-  issue_a(wrapx(x_lo + 2), raw, fix, w_raw, mall_raw);
+  issue_a(wrapx(x_lo + 2), raw, w_raw, mall_raw);
   lds_barrier();
   // steady state, branch-free around VMEM: the pulls of plane x + 3 are in flight while phase B of plane x + 1 runs.
   // The last two trips prefetch again plane x_hi (discarded): 2 / nx extra work, no branch.
@@ -768,13 +738,13 @@ __device__ __forceinline__ void step2_body(const StepArgs<T, S>& a, S* lds, unsi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XLB_TRACE(d, 4);
 #endif
-    finish_a(raw, fix, w_raw, mall_raw, d + 3, true);  // plane x + 2
+    finish_a(raw, w_raw, mall_raw, d + 3);  // plane x + 2
     XLB_TRACE(d, 5);
     w_raw = wa;
     // (KBC: keep the scheduler from hoisting the next plane's pulls above the collision — 27 more live registers there
     // put the fp64 body into scratch)
     if constexpr ((COLL & 3) != XLBHIP_BGK) __builtin_amdgcn_sched_barrier(0);
-    issue_a(wrapx(x + 3), raw, fix, w_raw, mall_raw);
+    issue_a(wrapx(x + 3), raw, w_raw, mall_raw);
     // the strips of plane x - 1 leave here, BEHIND the pulls just issued: the waves that write them (the last ones of the block, the
     // plane's critical path) next wait for vector memory a whole iteration later, when these stores have long been acknowledged.
     // (At the top of the iteration the stores were younger than the pulls finish_a waits for: their acknowledgement latency landed
