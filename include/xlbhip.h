@@ -143,7 +143,7 @@ int xlbhip_field_plane_upload(xlbhip_field* f, int population, int storage_plane
  * __cuda_array_interface__, the replacement of utils.py:340-447's ToJAX): bumps the contents version that the stepper's
  * per-mask caches (meta words, clean-item flags, end-plane scan) are keyed on */
 int xlbhip_field_touch(xlbhip_field* f);
-/* free / total device memory (hipMemGetInfo): the Python stepper refuses to pair reference-style calls when the
+/* (backend-internal, no reference counterpart) free / total device memory (hipMemGetInfo): the Python stepper refuses to pair reference-style calls when the
  * temporary third field a read of the virtual f(t+1) needs would not fit */
 int xlbhip_mem_info(xlbhip_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int xlbhip_field_info(const xlbhip_field* f, int* cardinality, int* nx, int* ny, int* nz, int* dtype, int* halo,
@@ -297,7 +297,8 @@ int xlbhip_comm_unique_id(void* out_id_bytes);     /* rank 0; broadcast by the h
 /* n_ranks == 1 with a non-NULL id creates a real one-rank RCCL communicator (self send/recv): used to
  * exercise the RCCL code path on a single GPU; with a NULL id the ghosts are refilled by device copies */
 int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_bytes, int periodic_x);
-/* The same exchange without RCCL: every rank exports the buffers it exchanges (hipIpcGetMemHandle) and PULLS the
+/* replaces: the same two lax.ppermute calls (xlb/distribute/distribute.py:31-41) as xlbhip_comm_init, by another transport.
+ * The same exchange without RCCL: every rank exports the buffers it exchanges (hipIpcGetMemHandle) and PULLS the
  * neighbours' planes on the communication stream — by one small copy kernel per exchange (option "ipc_copy" = 1, the
  * default: 8 blocks per plane, no LDS) or by plane-sized hipMemcpyAsync calls (= 0: copy engines, no compute unit;
  * "or hipMemcpyPeerAsync ... over xGMI").  Processes are ordered by sequence counters in a host
@@ -307,7 +308,8 @@ int xlbhip_comm_init(xlbhip_ctx* ctx, int rank, int n_ranks, const void* id_byte
  * fresh per job (the host side broadcasts a random one).  Ranks must exchange the same buffers in the same order. */
 int xlbhip_comm_init_ipc(xlbhip_ctx* ctx, int rank, int n_ranks, const char* token, int periodic_x);
 int xlbhip_comm_destroy(xlbhip_ctx* ctx);
-/* Telemetry of the slab protocol: the time the compute stream spent waiting for the halo event after the interior
+/* (no counterpart in the reference's JAX path; Neon's skeleton reports its overlap mode in the benchmark's JSON, mlups_3d.py:434-488)
+ * Telemetry of the slab protocol: the time the compute stream spent waiting for the halo event after the interior
  * launch, summed over `halo_waits` exchanges since the last reset (option "halo_telemetry", default on).  With a
  * working overlap it is the event overhead only (a few microseconds per exchange).  Blocking. */
 int xlbhip_comm_stats(xlbhip_ctx* ctx, double* halo_wait_ms, int64_t* halo_waits, int reset);
