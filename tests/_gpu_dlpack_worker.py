@@ -80,6 +80,17 @@ def edited_mask_is_seen():
     assert np.array_equal(bm.numpy(), o_bm2)
     f_0, f_1 = stepper.run(f_0, f_1, bm, mm, 1.3, 4)
     assert np.array_equal(f_0.numpy(), orc.run(e, o_bm2, o_mm, obcs, 1.3, lat, 4)), "edit of an exported bc_mask was not seen"
+    # ... and a POPULATION field edited through its alias: the two-step kernel keeps a strip buffer per field (the halo columns of
+    # its tiles), a cache of the field's contents; an exported field counts as modified on every use, so the strips are not trusted.
+    # The edit sits on a tile boundary of the (8 x 64) tiling with half-tile shift (z = 31 | 32), where stale strips would be pulled.
+    state = f_0.numpy()
+    t_f = torch.as_tensor(f_0, device="cuda")
+    t_f[:, 2:9, 3:11, 30:34] *= 1.001
+    torch.cuda.synchronize()
+    state[:, 2:9, 3:11, 30:34] *= np.float32(1.001)
+    assert np.array_equal(f_0.numpy(), state)
+    f_0, f_1 = stepper.run(f_0, f_1, bm, mm, 1.3, 4)
+    assert np.array_equal(f_0.numpy(), orc.run(state, o_bm2, o_mm, obcs, 1.3, lat, 4)), "edit of an exported population field was not seen (stale strips)"
     get_context().set_option("fuse2", 1)
 
 
