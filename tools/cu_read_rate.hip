@@ -60,6 +60,104 @@ __global__ void __launch_bounds__(THREADS) k_pull(const float* __restrict__ src,
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+
+// The same question for the TILE pattern of k_step2 ((8 x 64) tiles of a 512-cell-wide plane, marching along x): wave j < 8 of block b
+// pulls row j of its tile — 256 bytes, 2 KB from the next row — from Q populations per plane, and (STORE) writes the row of the
+// previous plane to a second set of arrays, as phase B does.  No arithmetic, no LDS traffic: what the memory system does with
+// this access pattern and this occupancy.  Variants: plain instead of non-temporal stores; stores before / after the pulls in
+// program order; a workgroup barrier between the plane's stores and its pulls (the phased order of k_step2); 1, 2 or 4 blocks per CU.
+template <int STORE /*0 none, 1 non-temporal, 2 plain*/, int ORDER /*0 pulls then stores, 1 stores then pulls, 2 stores | barrier | pulls*/>
+__global__ void __launch_bounds__(THREADS) k_tile(const float* __restrict__ src, float* __restrict__ dst, size_t pop_stride, size_t plane, int planes,
+                                                   float* out, int tz /*tile width in cells: 64 (8 x 64 tiles), 128 (4 x 128), 256, 512*/,
+                                                   int interleaved /*1: populations interleaved row by row, [x][y][l][z], instead of [l][x][y][z]*/) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // 512 cells per tile whatever its shape: ty = 512 / tz rows of tz cells, 512 / tz tiles across the plane's 512-cell rows
+  const int per_row = tz / 64, ty = 512 / tz, tiles_z = 512 / tz;
+  const int ty0 = (blockIdx.x / tiles_z) * ty, tz0 = (blockIdx.x % tiles_z) * tz;
+  size_t cell = (size_t)(ty0 + (wave & 7) / per_row) * 512 + tz0 + ((wave & 7) % per_row) * 64 + lane;
+  if (interleaved) {  // same bytes per population, plane and row; the Q rows (x, y, .) of the populations follow one another
+    cell = (size_t)(ty0 + (wave & 7) / per_row) * 512 * Q + tz0 + ((wave & 7) % per_row) * 64 + lane;
+    pop_stride = 512;
+    plane *= Q;
+  }
+  float acc = 0.f;
+  const bool active = wave < 8;
+  float v[Q], w[Q];
+  if (active) {
+#pragma unroll
+    for (int l = 0; l < Q; ++l) v[l] = src[(size_t)l * pop_stride + cell];
+  }
+  for (int x = 1; x < planes; ++x) {
+    if (active) {
+#pragma unroll
+      for (int l = 0; l < Q; ++l) w[l] = v[l];
+      auto pulls = [&]() {
+#pragma unroll
+        for (int l = 0; l < Q; ++l) v[l] = src[(size_t)l * pop_stride + (size_t)x * plane + cell];
+      };
+      auto stores = [&]() {
+#pragma unroll
+        for (int l = 0; l < Q; ++l) {
+          float* d = dst + (size_t)l * pop_stride + (size_t)(x - 1) * plane + cell;
+          if (STORE == 1)
+            __builtin_nontemporal_store(w[l] + 1.0f, d);
+          else if (STORE == 2)
+            *d = w[l] + 1.0f;
+          else
+            acc += w[l];
+        }
+      };
+      if (ORDER == 0) {
+        pulls();
+        __builtin_amdgcn_sched_barrier(0);
+        stores();
+      } else {
+        stores();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (ORDER == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (active && ORDER != 0) {
+#pragma unroll
+      for (int l = 0; l < Q; ++l) v[l] = src[(size_t)l * pop_stride + (size_t)x * plane + cell];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (active) {
+#pragma unroll
+    for (int l = 0; l < Q; ++l) acc += v[l];
+  }
+  if (acc == 12345.678f) lds[threadIdx.x] = acc;
+  out[(size_t)blockIdx.x * THREADS + threadIdx.x] = acc;
+}
+
+template <int STORE, int ORDER>
+static void run_tile(const float* src, float* dst, size_t pop_stride, float* out, int blocks_per_cu, const char* what, int tz = 64, int interleaved = 0) {
+  const size_t lds_bytes = (150 * 1024) / blocks_per_cu;
+  const int blocks = 256 * blocks_per_cu;
+  const size_t plane = (size_t)512 * (blocks / (512 / tz)) * (512 / tz);  // rows = tiles_y * ty
+  const int planes = (int)((pop_stride - 4096) / plane);
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<STORE, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_tile<STORE, ORDER>), dim3(blocks), dim3(THREADS), lds_bytes, 0, src, dst, pop_stride, plane, planes, out, tz, interleaved);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double rd = (double)blocks * planes * 8 * Q * 256.0, wr = STORE ? (double)blocks * (planes - 1) * 8 * Q * 256.0 : 0.0;
+  std::printf("(%d x %3d) tiles%s, %d block(s) per CU, %-44s read %7.1f + write %7.1f = %7.1f GB/s (%.3f ms)\n", 512 / tz, tz, interleaved ? ", populations interleaved by row" : "", blocks_per_cu, what, rd / (ms * 1e-3) / 1e9,
+              wr / (ms * 1e-3) / 1e9, (rd + wr) / (ms * 1e-3) / 1e9, ms);
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
 template <int DEPTH>
 static void run(const float* src, size_t pop_stride, float* out, unsigned long long* cyc, int blocks, size_t rows_per_block, int trips) {
   const size_t lds_bytes = 150 * 1024;
@@ -104,6 +202,27 @@ int main() {
     run<1>(src, pop_stride, out, cyc, blocks, rows_per_block, (int)(rows_per_block / waves / 1));
     run<2>(src, pop_stride, out, cyc, blocks, rows_per_block, (int)(rows_per_block / waves / 2) - 1);
     run<3>(src, pop_stride, out, cyc, blocks, rows_per_block, (int)(rows_per_block / waves / 3) - 1);
+  }
+  // tile pattern: pop_stride elements hold 512 x 256 x planes cells -> planes = 1024 (537 MB per population, as a 512^3 field)
+  float* dst;
+  CHECK(hipMalloc(&dst, Q * pop_stride * sizeof(float)));
+  CHECK(hipMemset(dst, 0, Q * pop_stride * sizeof(float)));
+  for (int bpc : {1, 2}) {
+    run_tile<0, 0>(src, dst, pop_stride, out, bpc, "pulls only");
+    run_tile<1, 0>(src, dst, pop_stride, out, bpc, "pulls, then non-temporal stores");
+    run_tile<2, 0>(src, dst, pop_stride, out, bpc, "pulls, then plain stores");
+    run_tile<1, 1>(src, dst, pop_stride, out, bpc, "non-temporal stores, then pulls");
+    run_tile<1, 2>(src, dst, pop_stride, out, bpc, "non-temporal stores | barrier | pulls");
+  }
+  for (int tz : {64, 512}) {
+    run_tile<0, 0>(src, dst, pop_stride, out, 1, "pulls only", tz, 1);
+    run_tile<1, 0>(src, dst, pop_stride, out, 1, "pulls, then non-temporal stores", tz, 1);
+    run_tile<1, 2>(src, dst, pop_stride, out, 1, "non-temporal stores | barrier | pulls", tz, 1);
+  }
+  for (int tz : {128, 256, 512}) {
+    run_tile<0, 0>(src, dst, pop_stride, out, 1, "pulls only", tz);
+    run_tile<1, 0>(src, dst, pop_stride, out, 1, "pulls, then non-temporal stores", tz);
+    run_tile<1, 2>(src, dst, pop_stride, out, 1, "non-temporal stores | barrier | pulls", tz);
   }
   return 0;
 }
