@@ -132,6 +132,118 @@ __global__ void __launch_bounds__(THREADS) k_tile(const float* __restrict__ src,
   out[(size_t)blockIdx.x * THREADS + threadIdx.x] = acc;
 }
 
+// BATCH planes per trip: the stores of BATCH planes, a barrier, the pulls of the next BATCH planes (longer runs of one direction
+// per CU); NTLOAD: non-temporal pulls.
+template <int BATCH, bool NTLOAD>
+__global__ void __launch_bounds__(THREADS) k_tile_batch(const float* __restrict__ src, float* __restrict__ dst, size_t pop_stride, size_t plane, int planes,
+                                                         float* out) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ty0 = (blockIdx.x / 8) * 8, tz0 = (blockIdx.x % 8) * 64;
+  const size_t cell = (size_t)(ty0 + (wave & 7)) * 512 + tz0 + lane;
+  const bool active = wave < 8;
+  float v[BATCH][Q];
+  float acc = 0.f;
+  auto pull = [&](int b, int x) {
+#pragma unroll
+    for (int l = 0; l < Q; ++l) {
+      const float* p = src + (size_t)l * pop_stride + (size_t)x * plane + cell;
+      v[b][l] = NTLOAD ? __builtin_nontemporal_load(p) : *p;
+    }
+  };
+  if (active)
+    for (int b = 0; b < BATCH; ++b) pull(b, b);
+  for (int x = BATCH; x + BATCH <= planes; x += BATCH) {
+    if (active) {
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b)
+#pragma unroll
+        for (int l = 0; l < Q; ++l) __builtin_nontemporal_store(v[b][l] + 1.0f, dst + (size_t)l * pop_stride + (size_t)(x - BATCH + b) * plane + cell);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (active) {
+#pragma unroll
+      for (int b = 0; b < BATCH; ++b) pull(b, x + b);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (active)
+    for (int b = 0; b < BATCH; ++b)
+#pragma unroll
+      for (int l = 0; l < Q; ++l) acc += v[b][l];
+  if (acc == 12345.678f) lds[threadIdx.x] = acc;
+  out[(size_t)blockIdx.x * THREADS + threadIdx.x] = acc;
+}
+
+// stores only, same rows
+__global__ void __launch_bounds__(THREADS) k_tile_store(float* __restrict__ dst, size_t pop_stride, size_t plane, int planes, int active_waves) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ty0 = (blockIdx.x / 8) * 8, tz0 = (blockIdx.x % 8) * 64;
+  if (threadIdx.x == 100000) lds[0] = 1.f;
+  // active_waves = 8: one row per wave; 4: two rows per wave (rows w and w + 4)
+  const int rows_per_wave = 8 / active_waves;
+  if (wave >= active_waves) return;
+  for (int x = 0; x < planes; ++x)
+    for (int r = 0; r < rows_per_wave; ++r) {
+      const size_t cell = (size_t)(ty0 + wave + r * active_waves) * 512 + tz0 + lane;
+#pragma unroll
+      for (int l = 0; l < Q; ++l) __builtin_nontemporal_store((float)(x + l), dst + (size_t)l * pop_stride + (size_t)x * plane + cell);
+    }
+}
+
+static void run_store(float* dst, size_t pop_stride, int blocks_per_cu, int active_waves) {
+  const size_t lds_bytes = (150 * 1024) / blocks_per_cu;
+  const int blocks = 256 * blocks_per_cu;
+  const size_t plane = (size_t)512 * (blocks / 8) * 8;
+  const int planes = (int)((pop_stride - 4096) / plane);
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_store), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_tile_store, dim3(blocks), dim3(THREADS), lds_bytes, 0, dst, pop_stride, plane, planes, active_waves);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = (double)blocks * planes * 8 * Q * 256.0;
+  std::printf("(8 x  64) tiles, %d block(s) per CU, %d storing waves per block, stores only: %7.1f GB/s (%.3f ms)\n", blocks_per_cu, active_waves,
+              bytes / (ms * 1e-3) / 1e9, ms);
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
+template <int BATCH, bool NTLOAD>
+static void run_batch(const float* src, float* dst, size_t pop_stride, float* out) {
+  const size_t lds_bytes = 150 * 1024;
+  const int blocks = 256;
+  const size_t plane = (size_t)512 * 256;
+  const int planes = (int)((pop_stride - 4096) / plane);
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_batch<BATCH, NTLOAD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_tile_batch<BATCH, NTLOAD>), dim3(blocks), dim3(THREADS), lds_bytes, 0, src, dst, pop_stride, plane, planes, out);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = 2.0 * blocks * (double)(planes / BATCH * BATCH) * 8 * Q * 256.0;
+  std::printf("(8 x  64) tiles, stores of %d plane(s) | barrier | %spulls of %d plane(s): %7.1f GB/s read + write (%.3f ms)\n", BATCH,
+              NTLOAD ? "non-temporal " : "", BATCH, bytes / (ms * 1e-3) / 1e9, ms);
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
 template <int STORE, int ORDER>
 static void run_tile(const float* src, float* dst, size_t pop_stride, float* out, int blocks_per_cu, const char* what, int tz = 64, int interleaved = 0) {
   const size_t lds_bytes = (150 * 1024) / blocks_per_cu;
@@ -214,6 +326,16 @@ int main() {
     run_tile<1, 1>(src, dst, pop_stride, out, bpc, "non-temporal stores, then pulls");
     run_tile<1, 2>(src, dst, pop_stride, out, bpc, "non-temporal stores | barrier | pulls");
   }
+  run_store(dst, pop_stride, 1, 8);
+  run_store(dst, pop_stride, 1, 4);
+  run_store(dst, pop_stride, 2, 8);
+  run_store(dst, pop_stride, 1, 8);
+  run_batch<1, false>(src, dst, pop_stride, out);
+  run_batch<1, true>(src, dst, pop_stride, out);
+  run_batch<2, false>(src, dst, pop_stride, out);
+  run_batch<3, false>(src, dst, pop_stride, out);
+  run_batch<1, false>(src, dst, pop_stride, out);
+  run_batch<2, false>(src, dst, pop_stride, out);
   for (int tz : {64, 512}) {
     run_tile<0, 0>(src, dst, pop_stride, out, 1, "pulls only", tz, 1);
     run_tile<1, 0>(src, dst, pop_stride, out, 1, "pulls, then non-temporal stores", tz, 1);
