@@ -8,7 +8,7 @@ LIB       ?= xlb_amd/lib/libxlbhip.so
 EXTRA     ?=
 HIPFLAGS  := $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function -Iinclude
 SRCS      := api.hip comm.cpp step_d2q9_bgk.hip step_d2q9_kbc.hip step_d3q19_bgk.hip step_d3q27_bgk.hip step_d3q27_kbc.hip step_d3q27_kbc_fast.hip \
-             step_d2q9_ext.hip step_d3q19_ext.hip step_d3q27_ext.hip step2_d3q19.hip step2_d3q19_strips.hip step2_d3q27.hip
+             step_d2q9_ext.hip step_d3q19_ext.hip step_d3q27_ext.hip step2_d3q19.hip step2_d3q19_strips.hip step2_d3q27.hip yardstick.hip
 OBJS      := $(addprefix $(OBJDIR)/,$(addsuffix .o,$(basename $(SRCS))))
 HDRS      := $(wildcard $(CSRC)/*.hpp) include/xlbhip.h
 

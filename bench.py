@@ -275,11 +275,11 @@ def cpu_baseline(args):
 def kernel_source_hash():
     """Hash of the sources that decide what the step kernels do and how they are launched (the kernels, their launchers
     and the scheduling logic of api.hip): PMC traffic figures in profiles/traffic.json are only quoted for the build
-    they were measured on.  (ops_kernels.hpp — whole-field operators, maskers — and comm.cpp are not part of it.)"""
+    they were measured on.  (ops_kernels.hpp — whole-field operators, maskers —, comm.cpp and yardstick.hip — bench.py's measurement copy — are not part of it.)"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "xlb_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hpp", ".hip", ".cpp")) and name not in ("ops_kernels.hpp", "comm.cpp", "comm.hpp", "common.hpp"):
+        if name.endswith((".hpp", ".hip", ".cpp")) and name not in ("ops_kernels.hpp", "comm.cpp", "comm.hpp", "common.hpp", "yardstick.hip"):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
@@ -406,6 +406,21 @@ def main():
         info = f_0.info()
         return 2 * info["plane_stride"] * vs.q * pp.store_precision.np_dtype(0).itemsize * 5 / (time.perf_counter() - t1) / 1e9
 
+    def pattern_copy_ms():
+        """ms for ONE copy of the field by a kernel with the two-step kernel's launch shape ((8 x 64) tiles, one block of 8 storing waves
+        per CU, stores | barrier | pulls per plane; csrc/ops_kernels.hpp k_copy_tiles): what the memory system gives such a launch,
+        without any arithmetic.  A fused pair moves the same algorithmic bytes (1 read + 1 write of the field)."""
+        try:
+            f_1.copy_tiles_from(f_0)
+        except Exception:  # noqa: BLE001 (shapes the tile copy does not take: no yardstick)
+            return None
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            f_1.copy_tiles_from(f_0)
+        ctx.sync()
+        return (time.perf_counter() - t1) / 5 * 1e3
+
     # (after the timed region by default; XLB_BENCH_YARDSTICK=before was an experiment — does a device that has just streamed 100 GB enter a
     # short timed region faster? no: the run-to-run spread, 2.35 / 2.50 ms per step on one box, is bimodal either way and moves with
     # time inside one process on unchanged allocations: tools/alloc_modes.py, profiles/r03/run_to_run_spread.md)
@@ -429,6 +444,7 @@ def main():
 
     if world == 1 and not yardstick_first:
         copy_gbs = copy_yardstick()
+    tiles_ms = pattern_copy_ms() if world == 1 and pp.store_precision.np_dtype(0).itemsize == 4 else None
 
     cells_total = float(np.prod(shape))
     local_cells = float(max(slab_bounds(shape[0], r, world)[1] for r in range(world))) * shape[1] * shape[2]
@@ -501,6 +517,10 @@ def main():
             "launch_ms": round(launch_ms, 4),  # what rocprofv3 reports per kernel launch
             "algorithmic_bytes_per_update": b_alg,
             "copy_yardstick_gbs": None if copy_gbs is None else round(copy_gbs, 1),
+            # the second yardstick (two-step launches only): a bare copy of the field with k_step2's launch shape — tiles, occupancy,
+            # phase order — and how much of its rate the launch reaches at equal algorithmic bytes (1 read + 1 write of the field)
+            "pattern_copy_ms": None if (tiles_ms is None or not fused2) else round(tiles_ms, 4),
+            "frac_of_pattern_copy": None if (tiles_ms is None or not fused2) else round(tiles_ms / launch_ms, 4),
             "kernel_source_hash": kernel_source_hash(),
         },
     }

@@ -133,6 +133,10 @@ int xlbhip_field_copy(xlbhip_field* dst, const xlbhip_field* src);            /*
 /* streaming copy by a plain kernel (4 or 16 bytes per lane): bandwidth yardstick and the
  * known-byte-count calibration of the rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/) */
 int xlbhip_field_copy_kernel(xlbhip_field* dst, const xlbhip_field* src, int bytes_per_lane);
+/* the same copy with the launch shape of the two-step kernel: one 704-thread block per CU, (8 x 64) tiles marching along x, a plane's
+ * stores and pulls separated by a barrier — the second yardstick of bench.py (roofline.pattern_copy_*); 4-byte elements, ny % 8 == 0,
+ * nz % 64 == 0.  Measurement only: nothing in the reference corresponds (its harness times the step alone, examples/performance/mlups_3d.py:225-242) */
+int xlbhip_field_copy_tiles(xlbhip_field* dst, const xlbhip_field* src);
 int xlbhip_field_upload(xlbhip_field* f, const void* host, size_t host_bytes);   /* interior only */
 int xlbhip_field_download(const xlbhip_field* f, void* host, size_t host_bytes); /* interior only; synchronous */
 /* one x-plane of one population, addressed by STORAGE plane (0 .. nx + 2 halo - 1, ghosts included):

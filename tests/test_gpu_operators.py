@@ -55,6 +55,22 @@ def test_grid_create_field(name, shape):
     assert np.array_equal(f.assign(a).numpy(), a)
 
 
+@pytest.mark.parametrize("halo", [0, 2])
+def test_yardstick_copies_copy(halo):
+    """bench.py's two copy yardsticks (the straight kernel copy and the one with the two-step kernel's launch shape) move every byte."""
+    init_hip("D3Q19")
+    grid = grid_factory((6, 16, 128), backend_config={"halo": halo} if halo else None)
+    a, b, c = (grid.create_field(cardinality=19) for _ in range(3))
+    rng = np.random.default_rng(1)
+    host = rng.random(a.shape, dtype=np.float32)
+    a.assign(host)
+    assert np.array_equal(b.copy_kernel_from(a, 16).numpy(), host)
+    assert np.array_equal(c.copy_tiles_from(a).numpy(), host)
+    bad = grid_factory((6, 12, 128)).create_field(cardinality=19)  # 12 rows: no whole (8 x 64) tiles
+    with pytest.raises(Exception, match="tiles"):
+        bad.copy_tiles_from(grid_factory((6, 12, 128)).create_field(cardinality=19))
+
+
 @pytest.mark.parametrize("name,shape", CASES)
 def test_equilibrium_rest_state(name, shape):
     # reference tests/kernels/equilibrium/test_equilibrium_warp.py

@@ -57,6 +57,7 @@ SIGNATURES = {
     "xlbhip_field_fill": [_p, _d],
     "xlbhip_field_copy": [_p, _p],
     "xlbhip_field_copy_kernel": [_p, _p, _i],
+    "xlbhip_field_copy_tiles": [_p, _p],
     "xlbhip_field_upload": [_p, _p, C.c_size_t],
     "xlbhip_field_download": [_p, _p, C.c_size_t],
     "xlbhip_field_plane_download": [_p, _i, _i, _p, C.c_size_t],
@@ -431,6 +432,11 @@ class Field:
 
     def copy_kernel_from(self, other, bytes_per_lane=16):
         check(load().xlbhip_field_copy_kernel(self.handle, other.handle, int(bytes_per_lane)))
+        return self
+
+    def copy_tiles_from(self, other):
+        """The copy with the two-step kernel's launch shape (bench.py's second yardstick)."""
+        check(load().xlbhip_field_copy_tiles(self.handle, other.handle))
         return self
 
     def info(self):
