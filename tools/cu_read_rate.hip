@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(THREADS) k_pull(const float* __restrict__ src,
 // previous plane to a second set of arrays, as phase B does.  No arithmetic, no LDS traffic: what the memory system does with
 // this access pattern and this occupancy.  Variants: plain instead of non-temporal stores; stores before / after the pulls in
 // program order; a workgroup barrier between the plane's stores and its pulls (the phased order of k_step2); 1, 2 or 4 blocks per CU.
-template <int STORE /*0 none, 1 non-temporal, 2 plain*/, int ORDER /*0 pulls then stores, 1 stores then pulls, 2 stores | barrier | pulls*/>
-__global__ void __launch_bounds__(THREADS) k_tile(const float* __restrict__ src, float* __restrict__ dst, size_t pop_stride, size_t plane, int planes,
+template <int STORE /*0 none, 1 non-temporal, 2 plain*/, int ORDER /*0 pulls then stores, 1 stores then pulls, 2 stores | barrier | pulls*/, int NT = THREADS>
+__global__ void __launch_bounds__(NT) k_tile(const float* __restrict__ src, float* __restrict__ dst, size_t pop_stride, size_t plane, int planes,
                                                    float* out, int tz /*tile width in cells: 64 (8 x 64 tiles), 128 (4 x 128), 256, 512*/,
                                                    int interleaved /*1: populations interleaved row by row, [x][y][l][z], instead of [l][x][y][z]*/) {
   extern __shared__ float lds[];
@@ -244,19 +244,19 @@ static void run_batch(const float* src, float* dst, size_t pop_stride, float* ou
   CHECK(hipEventDestroy(e1));
 }
 
-template <int STORE, int ORDER>
+template <int STORE, int ORDER, int NT = THREADS>
 static void run_tile(const float* src, float* dst, size_t pop_stride, float* out, int blocks_per_cu, const char* what, int tz = 64, int interleaved = 0) {
   const size_t lds_bytes = (150 * 1024) / blocks_per_cu;
   const int blocks = 256 * blocks_per_cu;
   const size_t plane = (size_t)512 * (blocks / (512 / tz)) * (512 / tz);  // rows = tiles_y * ty
   const int planes = (int)((pop_stride - 4096) / plane);
-  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<STORE, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile<STORE, ORDER, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   for (int rep = 0; rep < 2; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_tile<STORE, ORDER>), dim3(blocks), dim3(THREADS), lds_bytes, 0, src, dst, pop_stride, plane, planes, out, tz, interleaved);
+    hipLaunchKernelGGL((k_tile<STORE, ORDER, NT>), dim3(blocks), dim3(NT), lds_bytes, 0, src, dst, pop_stride, plane, planes, out, tz, interleaved);
     CHECK(hipGetLastError());
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
@@ -307,7 +307,7 @@ int main() {
   unsigned long long* cyc;
   CHECK(hipMalloc(&src, Q * pop_stride * sizeof(float)));
   CHECK(hipMemset(src, 0, Q * pop_stride * sizeof(float)));
-  CHECK(hipMalloc(&out, max_blocks * THREADS * sizeof(float)));
+  CHECK(hipMalloc(&out, 2048 * THREADS * sizeof(float)));  // (up to 1024 blocks in the many-waves runs)
   CHECK(hipMalloc(&cyc, max_blocks * sizeof(unsigned long long)));
   const int waves = THREADS / 64;
   for (int blocks : {256, 192, 128, 64, 32, 8}) {
@@ -336,6 +336,11 @@ int main() {
   run_batch<3, false>(src, dst, pop_stride, out);
   run_batch<1, false>(src, dst, pop_stride, out);
   run_batch<2, false>(src, dst, pop_stride, out);
+  // many waves per CU: 512-thread blocks (8 waves, all storing), 3 and 4 of them per CU (24 / 32 waves)
+  for (int bpc : {3, 4}) {
+    run_tile<1, 0, 512>(src, dst, pop_stride, out, bpc, "512-thread blocks: pulls, then stores");
+    run_tile<1, 2, 512>(src, dst, pop_stride, out, bpc, "512-thread blocks: stores | barrier | pulls");
+  }
   for (int tz : {64, 512}) {
     run_tile<0, 0>(src, dst, pop_stride, out, 1, "pulls only", tz, 1);
     run_tile<1, 0>(src, dst, pop_stride, out, 1, "pulls, then non-temporal stores", tz, 1);
