@@ -176,6 +176,65 @@ __global__ void __launch_bounds__(THREADS) k_tile_batch(const float* __restrict_
   out[(size_t)blockIdx.x * THREADS + threadIdx.x] = acc;
 }
 
+// the phased tile copy with 16-BYTE lanes: lane i of wave w moves cells 4 (i % 16) .. + 3 of tile row 4 w + i / 16 — a wave covers four
+// rows (1 KB per instruction), WAVES16 = 2 waves the tile; with 8 active waves each takes a quarter of the populations' planes instead
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int PLANES_PER_WAVE /*1: two active waves, every plane; 4: eight active waves, wave w takes planes x with x % 4 == w / 2*/>
+__global__ void __launch_bounds__(THREADS) k_tile16(const float* __restrict__ src, float* __restrict__ dst, size_t pop_stride, size_t plane, int planes) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ty0 = (blockIdx.x / 8) * 8, tz0 = (blockIdx.x % 8) * 64;
+  if (threadIdx.x == 100000) lds[0] = 1.f;
+  const bool active = PLANES_PER_WAVE == 1 ? wave < 2 : wave < 8;
+  const int half = wave & 1, phase = (wave >> 1) & 3;  // (idle waves run the same number of trips: the barrier counts arrivals)
+  const size_t cell = (size_t)(ty0 + 4 * half + lane / 16) * 512 + tz0 + 4 * (lane % 16);
+  f32x4 v[Q];
+  int x0 = PLANES_PER_WAVE == 1 ? 0 : phase;
+  if (active)
+#pragma unroll
+    for (int l = 0; l < Q; ++l) v[l] = *reinterpret_cast<const f32x4*>(src + (size_t)l * pop_stride + (size_t)x0 * plane + cell);
+  for (int x = x0 + PLANES_PER_WAVE; x < planes + PLANES_PER_WAVE; x += PLANES_PER_WAVE) {
+    if (active) {
+#pragma unroll
+      for (int l = 0; l < Q; ++l)
+        __builtin_nontemporal_store(v[l], reinterpret_cast<f32x4*>(dst + (size_t)l * pop_stride + (size_t)(x - PLANES_PER_WAVE) * plane + cell));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (active && x < planes) {
+#pragma unroll
+      for (int l = 0; l < Q; ++l) v[l] = *reinterpret_cast<const f32x4*>(src + (size_t)l * pop_stride + (size_t)x * plane + cell);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int PPW>
+static void run_tile16(const float* src, float* dst, size_t pop_stride) {
+  const size_t lds_bytes = 150 * 1024;
+  const int blocks = 256;
+  const size_t plane = (size_t)512 * 256;
+  const int planes = (int)((pop_stride - 4096) / plane) / 4 * 4;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile16<PPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_tile16<PPW>, dim3(blocks), dim3(THREADS), lds_bytes, 0, src, dst, pop_stride, plane, planes);
+    CHECK(hipGetLastError());
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  const double bytes = 2.0 * blocks * (double)planes * 8 * Q * 256.0;
+  std::printf("(8 x  64) tiles, 1 block per CU, 16-byte lanes, %d active waves, stores | barrier | pulls: %7.1f GB/s read + write (%.3f ms)\n",
+              PPW == 1 ? 2 : 8, bytes / (ms * 1e-3) / 1e9, ms);
+  CHECK(hipEventDestroy(e0));
+  CHECK(hipEventDestroy(e1));
+}
+
 // stores only, same rows
 __global__ void __launch_bounds__(THREADS) k_tile_store(float* __restrict__ dst, size_t pop_stride, size_t plane, int planes, int active_waves) {
   extern __shared__ float lds[];
@@ -336,6 +395,9 @@ int main() {
   run_batch<3, false>(src, dst, pop_stride, out);
   run_batch<1, false>(src, dst, pop_stride, out);
   run_batch<2, false>(src, dst, pop_stride, out);
+  run_tile16<1>(src, dst, pop_stride);
+  run_tile16<4>(src, dst, pop_stride);
+  run_tile16<1>(src, dst, pop_stride);
   // many waves per CU: 512-thread blocks (8 waves, all storing), 3 and 4 of them per CU (24 / 32 waves)
   for (int bpc : {3, 4}) {
     run_tile<1, 0, 512>(src, dst, pop_stride, out, bpc, "512-thread blocks: pulls, then stores");
